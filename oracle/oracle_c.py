@@ -1,0 +1,185 @@
+"""ctypes binding of oracle/libp2e_oracle.so (TEST INFRASTRUCTURE ONLY -- see p2e_oracle.h).
+
+numpy in / numpy out; column-major Goldilocks columns ``[col][n]`` (C-contiguous ``(ncols, n)`` uint64
+arrays), packed 256-bit values as ``(n, 32)`` uint8 little-endian.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+VERIFY_COLS = 82615
+GLV_MUL_COLS = 65243
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libp2e_oracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libp2e_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        for name in ("mul_witness", "checksum_witness", "add_witness", "sub_witness", "add_many_witness",
+                     "inv_witness", "glv_decompose", "limb_split", "limb_pack", "verify_witness",
+                     "glv_mul_witness"):
+            getattr(_LIB, "p2e_oracle_" + name).restype = C.c_long
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _cols(k, n):
+    return np.zeros((k, n), dtype=np.uint64)
+
+
+def _chk(a, k):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.ndim == 2 and a.shape[0] == k, a.shape
+    return a
+
+
+def mul_witness(field, x, y):
+    x, y = _chk(x, 9), _chk(y, 9)
+    n = x.shape[1]
+    r, q, cs, b = _cols(9, n), _cols(9, n), _cols(17, n), _cols(16, n)
+    err = np.zeros(n, dtype=np.uint8)
+    lib().p2e_oracle_mul_witness(C.c_int(field), _p(x), _p(y), _p(r), _p(q), _p(cs), _p(b), C.c_size_t(n),
+                                 C.c_size_t(n), _p(err))
+    return r, q, cs, b, err
+
+
+def checksum_witness(a):
+    a = _chk(a, 17)
+    n = a.shape[1]
+    b = _cols(16, n)
+    err = np.zeros(n, dtype=np.uint8)
+    lib().p2e_oracle_checksum_witness(_p(a), _p(b), C.c_size_t(n), C.c_size_t(n), _p(err))
+    return b, err
+
+
+def _binop(fn, field, a, b):
+    a, b = _chk(a, 9), _chk(b, 9)
+    n = a.shape[1]
+    out, ov = _cols(9, n), np.zeros(n, dtype=np.uint64)
+    err = np.zeros(n, dtype=np.uint8)
+    fn(C.c_int(field), _p(a), _p(b), _p(out), _p(ov), C.c_size_t(n), C.c_size_t(n), _p(err))
+    return out, ov, err
+
+
+def add_witness(field, a, b):
+    return _binop(lib().p2e_oracle_add_witness, field, a, b)
+
+
+def sub_witness(field, a, b):
+    return _binop(lib().p2e_oracle_sub_witness, field, a, b)
+
+
+def add_many_witness(field, summands):
+    s = np.ascontiguousarray(summands, dtype=np.uint64)
+    assert s.ndim == 3 and s.shape[1] == 9
+    k, _, n = s.shape
+    out, ov = _cols(9, n), np.zeros(n, dtype=np.uint64)
+    err = np.zeros(n, dtype=np.uint8)
+    lib().p2e_oracle_add_many_witness(C.c_int(field), _p(s), C.c_int(k), _p(out), _p(ov), C.c_size_t(n),
+                                      C.c_size_t(n), _p(err))
+    return out, ov, err
+
+
+def inv_witness(field, x):
+    x = _chk(x, 9)
+    n = x.shape[1]
+    inv, div = _cols(9, n), _cols(9, n)
+    err = np.zeros(n, dtype=np.uint8)
+    lib().p2e_oracle_inv_witness(C.c_int(field), _p(x), _p(inv), _p(div), C.c_size_t(n), C.c_size_t(n), _p(err))
+    return inv, div, err
+
+
+def glv_decompose(k):
+    k = _chk(k, 9)
+    n = k.shape[1]
+    k1, k2 = _cols(5, n), _cols(5, n)
+    n1, n2 = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    err = np.zeros(n, dtype=np.uint8)
+    lib().p2e_oracle_glv_decompose(_p(k), _p(k1), _p(k2), _p(n1), _p(n2), C.c_size_t(n), C.c_size_t(n), _p(err))
+    return k1, k2, n1, n2, err
+
+
+def limb_split(packed):
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    n = packed.shape[0]
+    out = _cols(9, n)
+    lib().p2e_oracle_limb_split(_p(packed), _p(out), C.c_size_t(n), C.c_size_t(n))
+    return out
+
+
+def limb_pack(limbs):
+    limbs = _chk(limbs, 9)
+    n = limbs.shape[1]
+    out = np.zeros((n, 32), dtype=np.uint8)
+    err = np.zeros(n, dtype=np.uint8)
+    lib().p2e_oracle_limb_pack(_p(limbs), _p(out), C.c_size_t(n), C.c_size_t(n), _p(err))
+    return out, err
+
+
+def verify_witness(msg, r, s, pkx, pky, nthreads=0):
+    arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (msg, r, s, pkx, pky)]
+    n = arrs[0].shape[0]
+    cols = _cols(VERIFY_COLS, n)
+    err = np.zeros(n, dtype=np.uint8)
+    flags = np.zeros(n, dtype=np.uint8)
+    lib().p2e_oracle_verify_witness(*[_p(a) for a in arrs], _p(cols), C.c_size_t(n), C.c_size_t(n), _p(err),
+                                    _p(flags), C.c_int(nthreads))
+    return cols, err, flags
+
+
+def glv_mul_witness(px, py, k, nthreads=0):
+    arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (px, py, k)]
+    n = arrs[0].shape[0]
+    cols = _cols(GLV_MUL_COLS, n)
+    err = np.zeros(n, dtype=np.uint8)
+    flags = np.zeros(n, dtype=np.uint8)
+    lib().p2e_oracle_glv_mul_witness(*[_p(a) for a in arrs], _p(cols), C.c_size_t(n), C.c_size_t(n), _p(err),
+                                     _p(flags), C.c_int(nthreads))
+    return cols, err, flags
+
+
+def rando():
+    x = np.zeros(32, dtype=np.uint8)
+    y = np.zeros(32, dtype=np.uint8)
+    lib().p2e_oracle_rando(_p(x), _p(y))
+    return int.from_bytes(x.tobytes(), "little"), int.from_bytes(y.tobytes(), "little")
+
+
+def max_threads():
+    return int(lib().p2e_oracle_max_threads())
+
+
+# helpers shared by tests
+def pack256(vals):
+    """list of python ints -> (n, 32) uint8 little-endian"""
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32).copy()
+
+
+def unpack256(arr):
+    return [int.from_bytes(bytes(row), "little") for row in np.asarray(arr, dtype=np.uint8)]
+
+
+def limbs_cols(vals, nl=9):
+    """list of python ints -> (nl, n) uint64 29-bit limb columns"""
+    out = np.zeros((nl, len(vals)), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        for k in range(nl):
+            out[k, i] = (int(v) >> (29 * k)) & ((1 << 29) - 1)
+    return out

@@ -1,0 +1,1016 @@
+/* C restatement of the plonky2-ecdsa hot-path witness generators -- TEST INFRASTRUCTURE ONLY.
+ * See p2e_oracle.h for the status header ("parity unpinned" vs literal reference outputs; pinned by
+ * the Python big-int restatement + the reference's constraint equations).
+ *
+ * Deliberately algorithm-faithful to the reference's CPU path and deliberately DIFFERENT from the
+ * product's HIP code: base-2^32 schoolbook multiplication + Knuth algorithm D division (what
+ * num::BigUint does), one Fermat exponentiation per inverse (plonky2 Secp256K1*::try_inverse =
+ * exp_biguint(order-2) [upstream-from-memory; in-tree template field/p256_base.rs:112-119]), affine
+ * incomplete curve formulas, one signature after another.  File:line citations are relative to
+ * /root/reference/src.
+ */
+#include "p2e_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef uint32_t w32;
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+#define NL 9
+#define BITS 29
+#define MASK29 ((1u << BITS) - 1)
+#define P_GL 0xFFFFFFFF00000001ull
+
+/* ------------------------------------------------------------------------------------------ */
+/* base-2^32 multi-precision helpers                                                            */
+/* ------------------------------------------------------------------------------------------ */
+static int bn_cmp(const w32 *a, const w32 *b, int n) {
+    for (int i = n - 1; i >= 0; i--) {
+        if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    }
+    return 0;
+}
+static int bn_is_zero(const w32 *a, int n) {
+    for (int i = 0; i < n; i++)
+        if (a[i]) return 0;
+    return 1;
+}
+static w32 bn_add(w32 *r, const w32 *a, const w32 *b, int n) {
+    u64 c = 0;
+    for (int i = 0; i < n; i++) {
+        c += (u64)a[i] + b[i];
+        r[i] = (w32)c;
+        c >>= 32;
+    }
+    return (w32)c;
+}
+static w32 bn_sub(w32 *r, const w32 *a, const w32 *b, int n) {
+    u64 br = 0;
+    for (int i = 0; i < n; i++) {
+        u64 d = (u64)a[i] - b[i] - br;
+        r[i] = (w32)d;
+        br = (d >> 63) & 1;
+    }
+    return (w32)br;
+}
+static void bn_mul(const w32 *a, int an, const w32 *b, int bn, w32 *r) {
+    memset(r, 0, sizeof(w32) * (size_t)(an + bn));
+    for (int i = 0; i < an; i++) {
+        u64 c = 0;
+        for (int j = 0; j < bn; j++) {
+            c += (u64)a[i] * b[j] + r[i + j];
+            r[i + j] = (w32)c;
+            c >>= 32;
+        }
+        r[i + bn] = (w32)c;
+    }
+}
+/* Knuth TAOCP vol.2 4.3.1 algorithm D.  u: un words, v: vn words (v[vn-1] != 0, vn >= 2), un >= vn.
+ * q: un-vn+1 words, r: vn words. */
+static void bn_divrem(const w32 *u, int un, const w32 *v, int vn, w32 *q, w32 *r) {
+    w32 un_[40], vn_[12];
+    int s = __builtin_clz(v[vn - 1]);
+    for (int i = vn - 1; i > 0; i--) vn_[i] = s ? (v[i] << s) | (v[i - 1] >> (32 - s)) : v[i];
+    vn_[0] = v[0] << s;
+    un_[un] = s ? u[un - 1] >> (32 - s) : 0;
+    for (int i = un - 1; i > 0; i--) un_[i] = s ? (u[i] << s) | (u[i - 1] >> (32 - s)) : u[i];
+    un_[0] = u[0] << s;
+    for (int j = un - vn; j >= 0; j--) {
+        u64 num = ((u64)un_[j + vn] << 32) | un_[j + vn - 1];
+        u64 qhat = num / vn_[vn - 1];
+        u64 rhat = num % vn_[vn - 1];
+        while (qhat >= (1ull << 32) || qhat * vn_[vn - 2] > ((rhat << 32) | un_[j + vn - 2])) {
+            qhat--;
+            rhat += vn_[vn - 1];
+            if (rhat >= (1ull << 32)) break;
+        }
+        /* multiply and subtract */
+        int64_t borrow = 0;
+        u64 carry = 0;
+        for (int i = 0; i < vn; i++) {
+            u64 p = qhat * vn_[i] + carry;
+            carry = p >> 32;
+            int64_t t = (int64_t)un_[i + j] - borrow - (int64_t)(p & 0xFFFFFFFFull);
+            un_[i + j] = (w32)t;
+            borrow = t < 0 ? 1 : 0;
+        }
+        int64_t t = (int64_t)un_[j + vn] - borrow - (int64_t)carry;
+        un_[j + vn] = (w32)t;
+        q[j] = (w32)qhat;
+        if (t < 0) { /* add back */
+            q[j]--;
+            u64 c = 0;
+            for (int i = 0; i < vn; i++) {
+                c += (u64)un_[i + j] + vn_[i];
+                un_[i + j] = (w32)c;
+                c >>= 32;
+            }
+            un_[j + vn] += (w32)c;
+        }
+    }
+    for (int i = 0; i < vn; i++) r[i] = s ? (un_[i] >> s) | ((u64)un_[i + 1] << (32 - s)) : un_[i];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* moduli and constants (curve/secp256k1.rs:15-38, curve/glv.rs:11-32)                          */
+/* ------------------------------------------------------------------------------------------ */
+static const w32 MOD_P[8] = {0xFFFFFC2F, 0xFFFFFFFE, 0xFFFFFFFF, 0xFFFFFFFF,
+                             0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF};
+static const w32 MOD_N[8] = {0xD0364141, 0xBFD25E8C, 0xAF48A03B, 0xBAAEDCE6,
+                             0xFFFFFFFE, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF};
+#define W64(x) (w32)((x) & 0xFFFFFFFFull), (w32)((x) >> 32)
+static const w32 GEN_X[8] = {W64(0x59F2815B16F81798ull), W64(0x029BFCDB2DCE28D9ull), W64(0x55A06295CE870B07ull),
+                             W64(0x79BE667EF9DCBBACull)};
+static const w32 GEN_Y[8] = {W64(0x9C47D08FFB10D4B8ull), W64(0xFD17B448A6855419ull), W64(0x5DA4FBFC0E1108A8ull),
+                             W64(0x483ADA7726A3C465ull)};
+static const w32 GLV_BETA[8] = {W64(13923278643952681454ull), W64(11308619431505398165ull),
+                                W64(7954561588662645993ull), W64(8856726876819556112ull)};
+static const w32 GLV_S[8] = {W64(16069571880186789234ull), W64(1310022930574435960ull),
+                             W64(11900229862571533402ull), W64(6008836872998760672ull)};
+static const w32 GLV_A1[8] = {W64(16747920425669159701ull), W64(3496713202691238861ull), 0, 0, 0, 0};
+static const w32 GLV_MINUS_B1[8] = {W64(8022177200260244675ull), W64(16448129721693014056ull), 0, 0, 0, 0};
+static const w32 GLV_A2[8] = {W64(6323353552219852760ull), W64(1498098850674701302ull), 1, 0, 0, 0};
+static const w32 GLV_B2[8] = {W64(16747920425669159701ull), W64(3496713202691238861ull), 0, 0, 0, 0};
+/* keccak256 of eight zero bytes, read as a little-endian integer (gadgets/curve_fixed_base.rs:34-37);
+ * tests/ re-derive this digest with oracle/p2e_ref.py's Keccak. */
+static const uint8_t HASH0_LE[32] = {0x01, 0x1b, 0x4d, 0x03, 0xdd, 0x8c, 0x01, 0xf1, 0x04, 0x91, 0x43,
+                                     0xcf, 0x9c, 0x4c, 0x81, 0x7e, 0x4b, 0x16, 0x7f, 0x1d, 0x1b, 0x83,
+                                     0xe5, 0xc6, 0xf0, 0xf1, 0x0d, 0x89, 0xba, 0x1e, 0x7b, 0xce};
+
+static const w32 *modulus_of(int field) { return field == P2E_O_FIELD_SCALAR ? MOD_N : MOD_P; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* prime-field ops the way the reference does them: BigUint mul + mod_floor, Fermat inverse     */
+/* ------------------------------------------------------------------------------------------ */
+static void fe_mulmod(w32 *r, const w32 *a, const w32 *b, const w32 *m) {
+    w32 prod[16], q[9];
+    bn_mul(a, 8, b, 8, prod);
+    bn_divrem(prod, 16, m, 8, q, r);
+}
+static void fe_addmod(w32 *r, const w32 *a, const w32 *b, const w32 *m) {
+    w32 c = bn_add(r, a, b, 8);
+    if (c || bn_cmp(r, m, 8) >= 0) bn_sub(r, r, m, 8);
+}
+static void fe_submod(w32 *r, const w32 *a, const w32 *b, const w32 *m) {
+    if (bn_sub(r, a, b, 8)) bn_add(r, r, m, 8);
+}
+static void fe_powmod(w32 *r, const w32 *a, const w32 *e, const w32 *m) {
+    w32 acc[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    int started = 0;
+    for (int i = 255; i >= 0; i--) {
+        if (started) fe_mulmod(acc, acc, acc, m);
+        if ((e[i >> 5] >> (i & 31)) & 1) {
+            fe_mulmod(acc, acc, a, m);
+            started = 1;
+        }
+    }
+    memcpy(r, acc, 32);
+}
+static void fe_invmod(w32 *r, const w32 *a, const w32 *m) {
+    w32 e[8], two[8] = {2, 0, 0, 0, 0, 0, 0, 0};
+    bn_sub(e, m, two, 8);
+    fe_powmod(r, a, e, m);
+}
+/* to_canonical_biguint: ONE conditional subtraction (template field/p256_base.rs:162-168) */
+static void fe_canon(w32 *a, const w32 *m) {
+    if (bn_cmp(a, m, 8) >= 0) bn_sub(a, a, m, 8);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* limb <-> word conversion (gadgets/biguint.rs:27-51 convert_base, :444-452 get_biguint_target) */
+/* ------------------------------------------------------------------------------------------ */
+/* sum limb_i * 2^(29 i) for arbitrary u64 limbs; returns 1 if the value does not fit nw words */
+static int limbs_to_words(const u64 *limbs, int nl, w32 *out, int nw) {
+    w32 acc[16];
+    memset(acc, 0, sizeof acc);
+    for (int i = 0; i < nl; i++) {
+        int bit = BITS * i;
+        int wi = bit >> 5, sh = bit & 31;
+        u128 v = (u128)limbs[i] << sh; /* up to 96 bits */
+        u64 c = 0;
+        for (int k = 0; k < 3 || c; k++) {
+            c += (u64)acc[wi + k] + (w32)(v & 0xFFFFFFFFu);
+            acc[wi + k] = (w32)c;
+            c >>= 32;
+            v >>= 32;
+            if (wi + k + 1 >= 16) break;
+        }
+    }
+    int over = 0;
+    for (int i = nw; i < 16; i++) over |= acc[i] != 0;
+    memcpy(out, acc, sizeof(w32) * (size_t)nw);
+    return over;
+}
+/* value -> nl 29-bit limbs; returns 1 if it does not fit */
+static int words_to_limbs(const w32 *w, int nw, u64 *limbs, int nl) {
+    int over = 0;
+    int total_bits = nw * 32;
+    for (int i = 0; i * BITS < total_bits || i < nl; i++) {
+        int bit = BITS * i;
+        u64 v = 0;
+        if (bit < total_bits) {
+            int wi = bit >> 5, sh = bit & 31;
+            u64 lo = w[wi];
+            u64 hi = wi + 1 < nw ? w[wi + 1] : 0;
+            v = ((lo | (hi << 32)) >> sh) & MASK29;
+        }
+        if (i < nl)
+            limbs[i] = v;
+        else if (v)
+            over = 1;
+    }
+    return over;
+}
+static void bytes_to_words(const uint8_t *b, w32 *w) {
+    for (int i = 0; i < 8; i++)
+        w[i] = (w32)b[4 * i] | ((w32)b[4 * i + 1] << 8) | ((w32)b[4 * i + 2] << 16) | ((w32)b[4 * i + 3] << 24);
+}
+static void words_to_bytes(const w32 *w, uint8_t *b) {
+    for (int i = 0; i < 8; i++) {
+        b[4 * i] = (uint8_t)w[i];
+        b[4 * i + 1] = (uint8_t)(w[i] >> 8);
+        b[4 * i + 2] = (uint8_t)(w[i] >> 16);
+        b[4 * i + 3] = (uint8_t)(w[i] >> 24);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Goldilocks                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+static u64 gl_reduce128(u128 x) {
+    u64 lo = (u64)x, hi = (u64)(x >> 64);
+    u64 hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
+    /* x = lo + hl*2^64 + hh*2^96 ;  2^64 = 2^32-1, 2^96 = -1  (mod p) */
+    u128 t = (u128)lo + (u128)hl * 0xFFFFFFFFull + (u128)P_GL - hh;
+    u64 tl = (u64)t, th = (u64)(t >> 64); /* th <= 1 */
+    u128 t2 = (u128)tl + (u128)th * 0xFFFFFFFFull;
+    u64 r = (u64)t2;
+    if ((u64)(t2 >> 64)) r += 0xFFFFFFFFull; /* cannot overflow again */
+    if (r >= P_GL) r -= P_GL;
+    return r;
+}
+static u64 gl_mul(u64 a, u64 b) { return gl_reduce128((u128)a * b); }
+static u64 gl_add(u64 a, u64 b) {
+    u128 s = (u128)a + b;
+    if (s >= P_GL) s -= P_GL;
+    return (u64)s;
+}
+static u64 gl_sub(u64 a, u64 b) { return a >= b ? a - b : a + (P_GL - b); }
+static u64 gl_pow(u64 a, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = gl_mul(r, a);
+        a = gl_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the generators, one element at a time                                                        */
+/* ------------------------------------------------------------------------------------------ */
+/* canonical value of a limb vector: from_noncanonical_biguint (err >= 2^256) + to_canonical */
+static int load_canon(const u64 *limbs, int nl, const w32 *m, w32 *out, uint8_t *err) {
+    if (limbs_to_words(limbs, nl, out, 8)) {
+        *err |= P2E_O_ERR_VALUE_GE_2_256;
+        memset(out, 0, 32);
+        return 1;
+    }
+    fe_canon(out, m);
+    return 0;
+}
+
+/* gadgets/nonnative.rs:626-645 */
+static void gen_add(const u64 *a, int na, const u64 *b, int nb, const w32 *m, u64 *sum, u64 *ov, uint8_t *err) {
+    w32 av[8], bv[8], s[9], m9[9];
+    int bad = load_canon(a, na, m, av, err) | load_canon(b, nb, m, bv, err);
+    s[8] = bn_add(s, av, bv, 8);
+    memcpy(m9, m, 32);
+    m9[8] = 0;
+    if (bn_cmp(s, m9, 9) > 0) { /* Q1: strict > */
+        bn_sub(s, s, m9, 9);
+        *ov = 1;
+    } else
+        *ov = 0;
+    words_to_limbs(s, 9, sum, NL);
+    if (bad) {
+        memset(sum, 0, sizeof(u64) * NL);
+        *ov = 0;
+    }
+}
+/* gadgets/nonnative.rs:792-810 */
+static void gen_sub(const u64 *a, int na, const u64 *b, int nb, const w32 *m, u64 *diff, u64 *ov, uint8_t *err) {
+    w32 av[8], bv[8], d[8];
+    int bad = load_canon(a, na, m, av, err) | load_canon(b, nb, m, bv, err);
+    if (bn_cmp(av, bv, 8) >= 0) {
+        bn_sub(d, av, bv, 8);
+        *ov = 0;
+    } else {
+        w32 t[8];
+        bn_sub(t, bv, av, 8);
+        bn_sub(d, m, t, 8);
+        *ov = 1;
+    }
+    words_to_limbs(d, 8, diff, NL);
+    if (bad) {
+        memset(diff, 0, sizeof(u64) * NL);
+        *ov = 0;
+    }
+}
+/* gadgets/nonnative.rs:696-728; summands[k] each with up to 9 limbs */
+static void gen_add_many(const u64 (*summands)[NL], const int *nls, int k, const w32 *m, u64 *sum, u64 *ov,
+                         uint8_t *err) {
+    w32 acc[12], q[5], r[8];
+    memset(acc, 0, sizeof acc);
+    int bad = 0;
+    for (int i = 0; i < k; i++) {
+        w32 v[12];
+        memset(v, 0, sizeof v);
+        bad |= load_canon(summands[i], nls[i], m, v, err);
+        bn_add(acc, acc, v, 12);
+    }
+    bn_divrem(acc, 12, m, 8, q, r);
+    *ov = q[0]; /* to_u64_digits()[0] as u32 */
+    words_to_limbs(r, 8, sum, NL);
+    if (bad) {
+        memset(sum, 0, sizeof(u64) * NL);
+        *ov = 0;
+    }
+}
+/* gadgets/nonnative.rs:857-872; outputs have k = nl limbs */
+static void gen_inv(const u64 *x, int nl, const w32 *m, u64 *inv, u64 *div, uint8_t *err) {
+    w32 xv[8], iv[8], prod[16], q[9], r[8];
+    memset(inv, 0, sizeof(u64) * (size_t)nl);
+    memset(div, 0, sizeof(u64) * (size_t)nl);
+    if (load_canon(x, nl, m, xv, err)) return;
+    if (bn_is_zero(xv, 8)) {
+        *err |= P2E_O_ERR_INVERSE_OF_ZERO;
+        return;
+    }
+    fe_invmod(iv, xv, m);
+    bn_mul(xv, 8, iv, 8, prod);
+    bn_divrem(prod, 16, m, 8, q, r);
+    if (words_to_limbs(iv, 8, inv, nl) | words_to_limbs(q, 9, div, nl)) *err |= P2E_O_ERR_LIMB_RANGE;
+}
+/* gates/mul_nonnative.rs:513-531 */
+static u64 INV_2_29;
+static void gen_checksum(const u64 *a, u64 *b, uint8_t *err) {
+    u64 last = 0;
+    for (int i = 0; i < 2 * NL - 2; i++) {
+        u64 bi = gl_mul(gl_add(a[i], last), INV_2_29);
+        u64 v = gl_add(bi, 1ull << 33);
+        b[i] = v;
+        last = bi;
+        if (v >= (1ull << 34)) *err |= P2E_O_ERR_CARRY_RANGE;
+    }
+}
+/* gates/mul_nonnative.rs:249-324; x, y are the 9 gate wires */
+static void gen_mul(const u64 *x, const u64 *y, const w32 *m, u64 *r29, u64 *q29, u64 *cs, uint8_t *err) {
+    w32 xv[9], yv[9], prod[18], q[11], r[8];
+    u64 m29[NL], q_full[13];
+    for (int i = 0; i < NL; i++) {
+        if (x[i] >> BITS || y[i] >> BITS) {
+            *err |= P2E_O_ERR_LIMB_RANGE;
+            memset(r29, 0, sizeof(u64) * NL);
+            memset(q29, 0, sizeof(u64) * NL);
+            memset(cs, 0, sizeof(u64) * (2 * NL - 1));
+            return;
+        }
+    }
+    limbs_to_words(x, NL, xv, 9);
+    limbs_to_words(y, NL, yv, 9);
+    bn_mul(xv, 9, yv, 9, prod);
+    bn_divrem(prod, 18, m, 8, q, r);
+    words_to_limbs(m, 8, m29, NL);
+    words_to_limbs(r, 8, r29, NL);
+    words_to_limbs(q, 11, q_full, 13);
+    for (int i = NL; i < 13; i++)
+        if (q_full[i]) *err |= P2E_O_ERR_QUOTIENT_RANGE; /* q does not fit the gate's 9 q wires */
+    memcpy(q29, q_full, sizeof(u64) * NL);
+    for (int i = 0; i < 2 * NL - 1; i++) {
+        int lo = i - NL + 1 > 0 ? i - NL + 1 : 0;
+        int hi = i + 1 < NL ? i + 1 : NL;
+        u64 acc = 0;
+        for (int j = lo; j < hi; j++) {
+            acc = gl_add(acc, gl_sub(gl_mul(q29[i - j], m29[j]), gl_mul(x[j], y[i - j])));
+        }
+        if (i < NL) acc = gl_add(acc, r29[i]);
+        cs[i] = acc;
+    }
+}
+/* curve/glv.rs:39-77 + gadgets/glv.rs:128-142 */
+static void glv_round_div(const w32 *c, const w32 *k, w32 *out /*8*/) {
+    /* round(c*k / n), num Ratio::round: n odd -> up iff 2*rem > n */
+    w32 prod[16], q[9], r[9], r2[9], n9[9];
+    bn_mul(c, 8, k, 8, prod);
+    bn_divrem(prod, 16, MOD_N, 8, q, r);
+    r[8] = 0;
+    memcpy(n9, MOD_N, 32);
+    n9[8] = 0;
+    bn_add(r2, r, r, 9);
+    if (bn_cmp(r2, n9, 9) > 0) {
+        w32 one[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0};
+        bn_add(q, q, one, 9);
+    }
+    memcpy(out, q, 32); /* < 2^130 */
+}
+static void gen_glv(const u64 *k_limbs, int nl, u64 *k1l, u64 *k2l, u64 *k1_neg, u64 *k2_neg, uint8_t *err) {
+    w32 k[8], c1[8], c2[8], t1[8], t2[8], k1[8], k2[8], half[8];
+    memset(k1l, 0, sizeof(u64) * 5);
+    memset(k2l, 0, sizeof(u64) * 5);
+    *k1_neg = *k2_neg = 0;
+    if (load_canon(k_limbs, nl, MOD_N, k, err)) return;
+    glv_round_div(GLV_B2, k, c1);
+    glv_round_div(GLV_MINUS_B1, k, c2);
+    fe_canon(c1, MOD_N);
+    fe_canon(c2, MOD_N);
+    fe_mulmod(t1, c1, GLV_A1, MOD_N);
+    fe_mulmod(t2, c2, GLV_A2, MOD_N);
+    fe_submod(k1, k, t1, MOD_N);
+    fe_submod(k1, k1, t2, MOD_N);
+    fe_mulmod(t1, c1, GLV_MINUS_B1, MOD_N);
+    fe_mulmod(t2, c2, GLV_B2, MOD_N);
+    fe_submod(k2, t1, t2, MOD_N);
+    for (int i = 0; i < 8; i++) half[i] = (MOD_N[i] >> 1) | (i < 7 ? MOD_N[i + 1] << 31 : 0);
+    if (bn_cmp(k1, half, 8) > 0) {
+        *k1_neg = 1;
+        bn_sub(k1, MOD_N, k1, 8);
+    }
+    if (bn_cmp(k2, half, 8) > 0) {
+        *k2_neg = 1;
+        bn_sub(k2, MOD_N, k2, 8);
+    }
+    if (words_to_limbs(k1, 8, k1l, 5) | words_to_limbs(k2, 8, k2l, 5)) *err |= P2E_O_ERR_LIMB_RANGE;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* native curve arithmetic for constants (curve/curve_types.rs:83-102, curve_adds.rs)           */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    w32 x[8], y[8];
+} apt;
+static void ec_double(apt *r, const apt *p) {
+    w32 l[8], t[8], u[8], x3[8];
+    fe_mulmod(t, p->x, p->x, MOD_P);
+    fe_addmod(u, t, t, MOD_P);
+    fe_addmod(t, u, t, MOD_P); /* 3x^2 */
+    fe_addmod(u, p->y, p->y, MOD_P);
+    fe_invmod(u, u, MOD_P);
+    fe_mulmod(l, t, u, MOD_P);
+    fe_mulmod(x3, l, l, MOD_P);
+    fe_submod(x3, x3, p->x, MOD_P);
+    fe_submod(x3, x3, p->x, MOD_P);
+    fe_submod(t, p->x, x3, MOD_P);
+    fe_mulmod(t, l, t, MOD_P);
+    fe_submod(r->y, t, p->y, MOD_P);
+    memcpy(r->x, x3, 32);
+}
+static void ec_add(apt *r, const apt *p, const apt *q) {
+    w32 l[8], t[8], u[8], x3[8];
+    fe_submod(t, q->y, p->y, MOD_P);
+    fe_submod(u, q->x, p->x, MOD_P);
+    fe_invmod(u, u, MOD_P);
+    fe_mulmod(l, t, u, MOD_P);
+    fe_mulmod(x3, l, l, MOD_P);
+    fe_submod(x3, x3, p->x, MOD_P);
+    fe_submod(x3, x3, q->x, MOD_P);
+    fe_submod(t, p->x, x3, MOD_P);
+    fe_mulmod(t, l, t, MOD_P);
+    fe_submod(r->y, t, p->y, MOD_P);
+    memcpy(r->x, x3, 32);
+}
+static void ec_neg(apt *r, const apt *p) {
+    w32 z[8] = {0};
+    memcpy(r->x, p->x, 32);
+    fe_submod(r->y, z, p->y, MOD_P);
+}
+static void ec_mul(apt *r, const w32 *k, const apt *p) {
+    apt acc, base = *p;
+    int have = 0;
+    for (int i = 0; i < 256; i++) {
+        if ((k[i >> 5] >> (i & 31)) & 1) {
+            if (have)
+                ec_add(&acc, &acc, &base);
+            else {
+                acc = base;
+                have = 1;
+            }
+        }
+        ec_double(&base, &base);
+    }
+    *r = acc;
+}
+
+#define FB_WINDOWS 66
+static apt RANDO, NEG_RANDO, NEG_RANDO_146;
+static u64 FB_TABLE[FB_WINDOWS][16][2][NL]; /* [window][digit][x|y][limb]; slot 0 := slot 1 */
+static u64 RANDO_L[2][NL], NEG_RANDO_L[2][NL], NEG_RANDO_146_L[2][NL], BETA_L[NL], GLV_S_L[NL], B7_L[NL];
+static int INIT_DONE = 0;
+
+static void point_limbs(const apt *p, u64 out[2][NL]) {
+    words_to_limbs(p->x, 8, out[0], NL);
+    words_to_limbs(p->y, 8, out[1], NL);
+}
+static void oracle_init(void) {
+#pragma omp critical(p2e_oracle_init)
+    {
+        if (!INIT_DONE) {
+            INV_2_29 = gl_pow(1ull << BITS, P_GL - 2);
+            apt g;
+            memcpy(g.x, GEN_X, 32);
+            memcpy(g.y, GEN_Y, 32);
+            w32 h[8];
+            bytes_to_words(HASH0_LE, h);
+            ec_mul(&RANDO, h, &g);
+            ec_neg(&NEG_RANDO, &RANDO);
+            apt d = RANDO;
+            for (int i = 0; i < 146; i++) ec_double(&d, &d); /* gadgets/curve_msm.rs:74 (2*73 doublings) */
+            ec_neg(&NEG_RANDO_146, &d);
+            point_limbs(&RANDO, RANDO_L);
+            point_limbs(&NEG_RANDO, NEG_RANDO_L);
+            point_limbs(&NEG_RANDO_146, NEG_RANDO_146_L);
+            words_to_limbs(GLV_BETA, 8, BETA_L, NL);
+            words_to_limbs(GLV_S, 8, GLV_S_L, NL);
+            memset(B7_L, 0, sizeof B7_L);
+            B7_L[0] = 7;
+            /* gadgets/curve_fixed_base.rs:24-30,45-56 */
+            apt base = g;
+            for (int w = 0; w < FB_WINDOWS; w++) {
+                apt acc = base;
+                for (int t = 1; t < 16; t++) {
+                    point_limbs(&acc, FB_TABLE[w][t]);
+                    if (t == 1) point_limbs(&acc, FB_TABLE[w][0]);
+                    if (t < 15) {
+                        if (t == 1)
+                            ec_double(&acc, &acc);
+                        else
+                            ec_add(&acc, &acc, &base);
+                    }
+                }
+                for (int i = 0; i < 4; i++) ec_double(&base, &base);
+            }
+            INIT_DONE = 1;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* walker: evaluates the gadget schedule for one element, emitting every generator output       */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    u64 l[NL];
+} nn; /* always padded to 9 limbs; limb *counts* never change a generator output on this path */
+typedef struct {
+    nn x, y;
+} pt;
+typedef struct {
+    u64 *out;
+    size_t ld, idx, col;
+    uint8_t err;
+} walker;
+
+static void emit(walker *w, const u64 *v, int n) {
+    for (int i = 0; i < n; i++) w->out[(w->col + (size_t)i) * w->ld + w->idx] = v[i];
+    w->col += (size_t)n;
+}
+static nn w_add(walker *w, const nn *a, const nn *b, int field) {
+    nn s;
+    u64 ov;
+    gen_add(a->l, NL, b->l, NL, modulus_of(field), s.l, &ov, &w->err);
+    emit(w, s.l, NL);
+    emit(w, &ov, 1);
+    return s;
+}
+static nn w_sub(walker *w, const nn *a, const nn *b, int field) {
+    nn d;
+    u64 ov;
+    gen_sub(a->l, NL, b->l, NL, modulus_of(field), d.l, &ov, &w->err);
+    emit(w, d.l, NL);
+    emit(w, &ov, 1);
+    return d;
+}
+static nn w_mul(walker *w, const nn *x, const nn *y, int field) {
+    nn r;
+    u64 q[NL], cs[2 * NL - 1], b[2 * NL - 2];
+    gen_mul(x->l, y->l, modulus_of(field), r.l, q, cs, &w->err);
+    gen_checksum(cs, b, &w->err);
+    emit(w, r.l, NL);
+    emit(w, q, NL);
+    emit(w, cs, 2 * NL - 1);
+    emit(w, b, 2 * NL - 2);
+    return r;
+}
+static nn w_inv(walker *w, const nn *x, int field) {
+    nn inv;
+    u64 div[NL];
+    gen_inv(x->l, NL, modulus_of(field), inv.l, div, &w->err);
+    emit(w, inv.l, NL);
+    emit(w, div, NL);
+    return inv;
+}
+static nn nn_zero(void) {
+    nn z;
+    memset(&z, 0, sizeof z);
+    return z;
+}
+static nn nn_from(const u64 *l) {
+    nn z;
+    memcpy(z.l, l, sizeof z.l);
+    return z;
+}
+static nn nn_mul_bool(const nn *a, u64 b) { /* gadgets/biguint.rs:360-374 */
+    nn r;
+    for (int i = 0; i < NL; i++) r.l[i] = gl_mul(a->l[i], b);
+    return r;
+}
+static nn w_cond_neg(walker *w, const nn *x, u64 b, int field) { /* gadgets/nonnative.rs:584-596 */
+    nn z = nn_zero();
+    nn neg = w_sub(w, &z, x, field);
+    nn t = nn_mul_bool(&neg, b), f = nn_mul_bool(x, 1 - b);
+    return w_add(w, &t, &f, field);
+}
+static pt w_curve_add(walker *w, const pt *p1, const pt *p2) { /* gadgets/curve.rs:202-223 */
+    const int F = P2E_O_FIELD_BASE;
+    nn u = w_sub(w, &p2->y, &p1->y, F);
+    nn v = w_sub(w, &p2->x, &p1->x, F);
+    nn vi = w_inv(w, &v, F);
+    nn s = w_mul(w, &u, &vi, F);
+    nn s2 = w_mul(w, &s, &s, F);
+    nn xs = w_add(w, &p2->x, &p1->x, F);
+    pt r;
+    r.x = w_sub(w, &s2, &xs, F);
+    nn xd = w_sub(w, &p1->x, &r.x, F);
+    nn pr = w_mul(w, &s, &xd, F);
+    r.y = w_sub(w, &pr, &p1->y, F);
+    return r;
+}
+static pt w_curve_double(walker *w, const pt *p) { /* gadgets/curve.rs:160-185 */
+    const int F = P2E_O_FIELD_BASE;
+    nn dy = w_add(w, &p->y, &p->y, F);
+    nn idy = w_inv(w, &dy, F);
+    nn xx = w_mul(w, &p->x, &p->x, F);
+    u64 summ[4][NL];
+    int nls[4] = {NL, NL, NL, 0};
+    memcpy(summ[0], xx.l, sizeof xx.l);
+    memcpy(summ[1], xx.l, sizeof xx.l);
+    memcpy(summ[2], xx.l, sizeof xx.l);
+    memset(summ[3], 0, sizeof summ[3]); /* A = 0 */
+    nn t;
+    u64 ov;
+    gen_add_many((const u64(*)[NL])summ, nls, 4, MOD_P, t.l, &ov, &w->err);
+    emit(w, t.l, NL);
+    emit(w, &ov, 1);
+    nn l = w_mul(w, &t, &idy, F);
+    nn l2 = w_mul(w, &l, &l, F);
+    nn xd2 = w_add(w, &p->x, &p->x, F);
+    pt r;
+    r.x = w_sub(w, &l2, &xd2, F);
+    nn xdf = w_sub(w, &p->x, &r.x, F);
+    nn lx = w_mul(w, &l, &xdf, F);
+    r.y = w_sub(w, &lx, &p->y, F);
+    return r;
+}
+static pt w_curve_cond_add(walker *w, const pt *p1, const pt *p2, u64 b) { /* gadgets/curve.rs:225-243 */
+    pt s = w_curve_add(w, p1, p2);
+    nn xt = nn_mul_bool(&s.x, b), xf = nn_mul_bool(&p1->x, 1 - b);
+    nn yt = nn_mul_bool(&s.y, b), yf = nn_mul_bool(&p1->y, 1 - b);
+    pt r;
+    r.x = w_add(w, &xt, &xf, P2E_O_FIELD_BASE);
+    r.y = w_add(w, &yt, &yf, P2E_O_FIELD_BASE);
+    return r;
+}
+static pt pt_from(u64 l[2][NL]) {
+    pt p;
+    memcpy(p.x.l, l[0], sizeof p.x.l);
+    memcpy(p.y.l, l[1], sizeof p.y.l);
+    return p;
+}
+/* digit t of width wbits (2 or 4) of a limb vector: bits of each 29-bit limb LE, limb-major
+ * (gadgets/split_nonnative.rs:25-72) */
+static unsigned digit_of(const u64 *limbs, int nl, int wbits, int t) {
+    unsigned d = 0;
+    for (int k = 0; k < wbits; k++) {
+        int bit = t * wbits + k;
+        int li = bit / BITS;
+        if (li < nl) d |= (unsigned)((limbs[li] >> (bit % BITS)) & 1) << k;
+    }
+    return d;
+}
+static pt w_fixed_base(walker *w, const nn *scalar) { /* gadgets/curve_fixed_base.rs:18-66 */
+    pt result = pt_from(RANDO_L);
+    for (int i = 0; i < FB_WINDOWS; i++) {
+        unsigned d = digit_of(scalar->l, NL, 4, i);
+        pt r = pt_from(FB_TABLE[i][d]);
+        result = w_curve_cond_add(w, &result, &r, d != 0);
+    }
+    pt nr = pt_from(NEG_RANDO_L);
+    return w_curve_add(w, &result, &nr);
+}
+static pt w_msm(walker *w, const pt *p, const pt *q, const u64 *n5, const u64 *m5) { /* gadgets/curve_msm.rs:21-79 */
+    pt pre[16];
+    pt rando = pt_from(RANDO_L), nr = pt_from(NEG_RANDO_L);
+    for (int i = 0; i < 16; i++) pre[i] = *p;
+    pt cur_p = rando, cur_q = rando;
+    for (int i = 0; i < 4; i++) {
+        pre[i] = cur_p;
+        pre[4 * i] = cur_q;
+        cur_p = w_curve_add(w, &cur_p, p);
+        cur_q = w_curve_add(w, &cur_q, q);
+    }
+    for (int i = 1; i < 4; i++) {
+        pre[i] = w_curve_add(w, &pre[i], &nr);
+        pre[4 * i] = w_curve_add(w, &pre[4 * i], &nr);
+    }
+    for (int i = 1; i < 4; i++)
+        for (int j = 1; j < 4; j++) pre[i + 4 * j] = w_curve_add(w, &pre[i], &pre[4 * j]);
+    pt result = rando;
+    for (int d = 72; d >= 0; d--) { /* 5 limbs -> 145 bits -> 146 -> 73 digits, MSB first */
+        result = w_curve_double(w, &result);
+        result = w_curve_double(w, &result);
+        unsigned idx = 4 * digit_of(m5, 5, 2, d) + digit_of(n5, 5, 2, d);
+        result = w_curve_cond_add(w, &result, &pre[idx], idx != 0);
+    }
+    pt to_add = pt_from(NEG_RANDO_146_L);
+    return w_curve_add(w, &result, &to_add);
+}
+static int nn_eq(const nn *a, const nn *b) { return memcmp(a->l, b->l, sizeof a->l) == 0; }
+static pt w_glv_mul(walker *w, const pt *p, const nn *k, int *ok) { /* gadgets/glv.rs:53-104 */
+    const int S = P2E_O_FIELD_SCALAR;
+    nn k1 = nn_zero(), k2 = nn_zero();
+    u64 n1, n2;
+    gen_glv(k->l, NL, k1.l, k2.l, &n1, &n2, &w->err);
+    emit(w, k1.l, 5);
+    emit(w, k2.l, 5);
+    emit(w, &n1, 1);
+    emit(w, &n2, 1);
+    nn k1r = w_cond_neg(w, &k1, n1, S);
+    nn k2r = w_cond_neg(w, &k2, n2, S);
+    nn gs = nn_from(GLV_S_L);
+    nn sb = w_mul(w, &gs, &k2r, S);
+    sb = w_add(w, &sb, &k1r, S);
+    *ok &= nn_eq(&sb, k);
+    nn beta = nn_from(BETA_L);
+    pt sp;
+    sp.x = w_mul(w, &beta, &p->x, P2E_O_FIELD_BASE);
+    sp.y = p->y;
+    pt pn, spn;
+    pn.x = p->x;
+    pn.y = w_cond_neg(w, &p->y, n1, P2E_O_FIELD_BASE);
+    spn.x = sp.x;
+    spn.y = w_cond_neg(w, &sp.y, n2, P2E_O_FIELD_BASE);
+    return w_msm(w, &pn, &spn, k1.l, k2.l);
+}
+static nn nn_from_bytes(const uint8_t *b) {
+    w32 wv[8];
+    nn r;
+    bytes_to_words(b, wv);
+    words_to_limbs(wv, 8, r.l, NL);
+    return r;
+}
+static void walk_verify(walker *w, const uint8_t *msg32, const uint8_t *r32, const uint8_t *s32,
+                        const uint8_t *pkx32, const uint8_t *pky32, uint8_t *flag) { /* gadgets/ecdsa.rs:30-53 */
+    const int F = P2E_O_FIELD_BASE, S = P2E_O_FIELD_SCALAR;
+    nn msg = nn_from_bytes(msg32), r = nn_from_bytes(r32), s = nn_from_bytes(s32);
+    pt pk;
+    pk.x = nn_from_bytes(pkx32);
+    pk.y = nn_from_bytes(pky32);
+    int ok = 1;
+    /* curve_assert_valid gadgets/curve.rs:123-135 */
+    nn a0 = nn_zero(), b7 = nn_from(B7_L);
+    nn y2 = w_mul(w, &pk.y, &pk.y, F);
+    nn x2 = w_mul(w, &pk.x, &pk.x, F);
+    nn x3 = w_mul(w, &x2, &pk.x, F);
+    nn ax = w_mul(w, &a0, &pk.x, F);
+    nn axb = w_add(w, &ax, &b7, F);
+    nn rhs = w_add(w, &x3, &axb, F);
+    ok &= nn_eq(&y2, &rhs);
+    nn c = w_inv(w, &s, S);
+    nn u1 = w_mul(w, &msg, &c, S);
+    nn u2 = w_mul(w, &r, &c, S);
+    pt p1 = w_fixed_base(w, &u1);
+    pt p2 = w_glv_mul(w, &pk, &u2, &ok);
+    pt sum = w_curve_add(w, &p1, &p2);
+    ok &= nn_eq(&sum.x, &r);
+    *flag = (uint8_t)ok;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* batch entry points                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+static void gather(const u64 *base, size_t ld, size_t i, u64 *out, int n) {
+    for (int k = 0; k < n; k++) out[k] = base[(size_t)k * ld + i];
+}
+static void scatter(u64 *base, size_t ld, size_t i, const u64 *in, int n) {
+    for (int k = 0; k < n; k++) base[(size_t)k * ld + i] = in[k];
+}
+static long count_err(const uint8_t *err, size_t n) {
+    long c = 0;
+    for (size_t i = 0; i < n; i++) c += err[i] != 0;
+    return c;
+}
+
+long p2e_oracle_mul_witness(int field, const uint64_t *x, const uint64_t *y, uint64_t *r, uint64_t *q,
+                            uint64_t *cs, uint64_t *b, size_t n, size_t ld, uint8_t *err) {
+    oracle_init();
+    const w32 *m = modulus_of(field);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        u64 xl[NL], yl[NL], rl[NL], ql[NL], csl[2 * NL - 1], bl[2 * NL - 2];
+        uint8_t e = 0;
+        gather(x, ld, i, xl, NL);
+        gather(y, ld, i, yl, NL);
+        gen_mul(xl, yl, m, rl, ql, csl, &e);
+        memset(bl, 0, sizeof bl);
+        if (!e) gen_checksum(csl, bl, &e);
+        scatter(r, ld, i, rl, NL);
+        scatter(q, ld, i, ql, NL);
+        scatter(cs, ld, i, csl, 2 * NL - 1);
+        scatter(b, ld, i, bl, 2 * NL - 2);
+        err[i] = e;
+    }
+    return count_err(err, n);
+}
+long p2e_oracle_checksum_witness(const uint64_t *a, uint64_t *b, size_t n, size_t ld, uint8_t *err) {
+    oracle_init();
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        u64 al[2 * NL - 1], bl[2 * NL - 2];
+        uint8_t e = 0;
+        gather(a, ld, i, al, 2 * NL - 1);
+        gen_checksum(al, bl, &e);
+        scatter(b, ld, i, bl, 2 * NL - 2);
+        err[i] = e;
+    }
+    return count_err(err, n);
+}
+long p2e_oracle_add_witness(int field, const uint64_t *a, const uint64_t *b, uint64_t *sum, uint64_t *ov,
+                            size_t n, size_t ld, uint8_t *err) {
+    oracle_init();
+    const w32 *m = modulus_of(field);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        u64 al[NL], bl[NL], sl[NL], o;
+        uint8_t e = 0;
+        gather(a, ld, i, al, NL);
+        gather(b, ld, i, bl, NL);
+        gen_add(al, NL, bl, NL, m, sl, &o, &e);
+        scatter(sum, ld, i, sl, NL);
+        ov[i] = o;
+        err[i] = e;
+    }
+    return count_err(err, n);
+}
+long p2e_oracle_sub_witness(int field, const uint64_t *a, const uint64_t *b, uint64_t *diff, uint64_t *ov,
+                            size_t n, size_t ld, uint8_t *err) {
+    oracle_init();
+    const w32 *m = modulus_of(field);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        u64 al[NL], bl[NL], dl[NL], o;
+        uint8_t e = 0;
+        gather(a, ld, i, al, NL);
+        gather(b, ld, i, bl, NL);
+        gen_sub(al, NL, bl, NL, m, dl, &o, &e);
+        scatter(diff, ld, i, dl, NL);
+        ov[i] = o;
+        err[i] = e;
+    }
+    return count_err(err, n);
+}
+long p2e_oracle_add_many_witness(int field, const uint64_t *summands, int k, uint64_t *sum, uint64_t *ov,
+                                 size_t n, size_t ld, uint8_t *err) {
+    oracle_init();
+    const w32 *m = modulus_of(field);
+    if (k < 1 || k > 8) return -1;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        u64 sm[8][NL], sl[NL], o;
+        int nls[8];
+        uint8_t e = 0;
+        for (int t = 0; t < k; t++) {
+            gather(summands + (size_t)t * NL * ld, ld, i, sm[t], NL);
+            nls[t] = NL;
+        }
+        gen_add_many((const u64(*)[NL])sm, nls, k, m, sl, &o, &e);
+        scatter(sum, ld, i, sl, NL);
+        ov[i] = o;
+        err[i] = e;
+    }
+    return count_err(err, n);
+}
+long p2e_oracle_inv_witness(int field, const uint64_t *x, uint64_t *inv, uint64_t *div, size_t n, size_t ld,
+                            uint8_t *err) {
+    oracle_init();
+    const w32 *m = modulus_of(field);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t i = 0; i < n; i++) {
+        u64 xl[NL], il[NL], dl[NL];
+        uint8_t e = 0;
+        gather(x, ld, i, xl, NL);
+        gen_inv(xl, NL, m, il, dl, &e);
+        scatter(inv, ld, i, il, NL);
+        scatter(div, ld, i, dl, NL);
+        err[i] = e;
+    }
+    return count_err(err, n);
+}
+long p2e_oracle_glv_decompose(const uint64_t *k, uint64_t *k1, uint64_t *k2, uint64_t *k1_neg,
+                              uint64_t *k2_neg, size_t n, size_t ld, uint8_t *err) {
+    oracle_init();
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        u64 kl[NL], a[5], b[5], n1, n2;
+        uint8_t e = 0;
+        gather(k, ld, i, kl, NL);
+        gen_glv(kl, NL, a, b, &n1, &n2, &e);
+        scatter(k1, ld, i, a, 5);
+        scatter(k2, ld, i, b, 5);
+        k1_neg[i] = n1;
+        k2_neg[i] = n2;
+        err[i] = e;
+    }
+    return count_err(err, n);
+}
+long p2e_oracle_limb_split(const uint8_t *packed, uint64_t *limbs, size_t n, size_t ld) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        nn v = nn_from_bytes(packed + 32 * i);
+        scatter(limbs, ld, i, v.l, NL);
+    }
+    return 0;
+}
+long p2e_oracle_limb_pack(const uint64_t *limbs, uint8_t *packed, size_t n, size_t ld, uint8_t *err) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        u64 l[NL];
+        w32 w[8];
+        uint8_t e = 0;
+        gather(limbs, ld, i, l, NL);
+        for (int k = 0; k < NL; k++)
+            if (l[k] >> BITS) e |= P2E_O_ERR_LIMB_RANGE;
+        if (limbs_to_words(l, NL, w, 8)) e |= P2E_O_ERR_VALUE_GE_2_256;
+        if (e) memset(w, 0, sizeof w);
+        words_to_bytes(w, packed + 32 * i);
+        err[i] = e;
+    }
+    return count_err(err, n);
+}
+
+long p2e_oracle_verify_witness(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
+                               const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint8_t *err,
+                               uint8_t *flags, int nthreads) {
+    oracle_init();
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t i = 0; i < n; i++) {
+        walker w = {cols, ld, i, 0, 0};
+        uint8_t f = 0;
+        walk_verify(&w, msg + 32 * i, r + 32 * i, s + 32 * i, pkx + 32 * i, pky + 32 * i, &f);
+        err[i] = w.err;
+        if (flags) flags[i] = f;
+    }
+    return count_err(err, n);
+}
+long p2e_oracle_glv_mul_witness(const uint8_t *px, const uint8_t *py, const uint8_t *k, uint64_t *cols,
+                                size_t n, size_t ld, uint8_t *err, uint8_t *flags, int nthreads) {
+    oracle_init();
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t i = 0; i < n; i++) {
+        walker w = {cols, ld, i, 0, 0};
+        pt p;
+        p.x = nn_from_bytes(px + 32 * i);
+        p.y = nn_from_bytes(py + 32 * i);
+        nn kk = nn_from_bytes(k + 32 * i);
+        int ok = 1;
+        (void)w_glv_mul(&w, &p, &kk, &ok);
+        err[i] = w.err;
+        if (flags) flags[i] = (uint8_t)ok;
+    }
+    return count_err(err, n);
+}
+void p2e_oracle_rando(uint8_t x32[32], uint8_t y32[32]) {
+    oracle_init();
+    words_to_bytes(RANDO.x, x32);
+    words_to_bytes(RANDO.y, y32);
+}
+int p2e_oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,78 @@
+/* C restatement of the plonky2-ecdsa hot-path witness generators -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this.  The
+ * product path (plonky2-ecdsa_amd/, include/p2e.h) never does.
+ *
+ * PARITY STATUS: "parity unpinned" against literal reference outputs (the reference holds no golden
+ * vectors for these generators and cannot be built offline: SURVEY.md 8c).  Pinned instead by
+ * (i) agreement with the independent Python big-int restatement oracle/p2e_ref.py on the committed
+ * fixtures tests/golden/ (ii) the reference's constraint equations, re-evaluated in tests/.
+ *
+ * Data layout (same as include/p2e.h): Goldilocks-canonical u64 columns, column-major over the
+ * batch: element (col, i) lives at base[col * ld + i], ld >= n.  256-bit inputs are packed 32-byte
+ * little-endian, element i at base + 32*i.
+ */
+#ifndef P2E_ORACLE_H
+#define P2E_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2E_O_FIELD_BASE 0   /* Secp256K1Base   */
+#define P2E_O_FIELD_SCALAR 1 /* Secp256K1Scalar */
+
+#define P2E_O_ERR_LIMB_RANGE 1
+#define P2E_O_ERR_VALUE_GE_2_256 2
+#define P2E_O_ERR_INVERSE_OF_ZERO 4
+#define P2E_O_ERR_CARRY_RANGE 8
+#define P2E_O_ERR_QUOTIENT_RANGE 16
+
+#define P2E_O_VERIFY_COLS 82615
+#define P2E_O_GLV_MUL_COLS 65243
+
+/* each returns the number of elements with err != 0 */
+/* gates/mul_nonnative.rs:249-324 + :513-531 : x[9][n], y[9][n] -> r[9], q[9], cs[17], b[16] */
+long p2e_oracle_mul_witness(int field, const uint64_t *x, const uint64_t *y, uint64_t *r, uint64_t *q,
+                            uint64_t *cs, uint64_t *b, size_t n, size_t ld, uint8_t *err);
+/* gates/mul_nonnative.rs:513-531 alone: a[17][n] -> b[16][n] (true Goldilocks field division) */
+long p2e_oracle_checksum_witness(const uint64_t *a, uint64_t *b, size_t n, size_t ld, uint8_t *err);
+/* gadgets/nonnative.rs:626-645 : a[9][n], b[9][n] -> sum[9][n], overflow[n] */
+long p2e_oracle_add_witness(int field, const uint64_t *a, const uint64_t *b, uint64_t *sum, uint64_t *ov,
+                            size_t n, size_t ld, uint8_t *err);
+/* gadgets/nonnative.rs:792-810 */
+long p2e_oracle_sub_witness(int field, const uint64_t *a, const uint64_t *b, uint64_t *diff, uint64_t *ov,
+                            size_t n, size_t ld, uint8_t *err);
+/* gadgets/nonnative.rs:696-728 : summands[k][9][n] */
+long p2e_oracle_add_many_witness(int field, const uint64_t *summands, int k, uint64_t *sum, uint64_t *ov,
+                                 size_t n, size_t ld, uint8_t *err);
+/* gadgets/nonnative.rs:857-872 : x[9][n] -> inv[9][n], div[9][n] */
+long p2e_oracle_inv_witness(int field, const uint64_t *x, uint64_t *inv, uint64_t *div, size_t n, size_t ld,
+                            uint8_t *err);
+/* gadgets/glv.rs:128-142 : k[9][n] -> k1[5][n], k2[5][n], k1_neg[n], k2_neg[n] */
+long p2e_oracle_glv_decompose(const uint64_t *k, uint64_t *k1, uint64_t *k2, uint64_t *k1_neg,
+                              uint64_t *k2_neg, size_t n, size_t ld, uint8_t *err);
+/* gadgets/biguint.rs:27-51,454-463 : packed 32-byte LE -> limbs[9][n] and back (pack flags limbs >= 2^29
+ * or value >= 2^256) */
+long p2e_oracle_limb_split(const uint8_t *packed, uint64_t *limbs, size_t n, size_t ld);
+long p2e_oracle_limb_pack(const uint64_t *limbs, uint8_t *packed, size_t n, size_t ld, uint8_t *err);
+
+/* gadgets/ecdsa.rs:30-53 : cols[82615][n].  flags[i] bit0 = all three connect constraints hold
+ * (curve_assert_valid, glv k reconstruction, r == x). nthreads <= 0 -> omp default. */
+long p2e_oracle_verify_witness(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
+                               const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint8_t *err,
+                               uint8_t *flags, int nthreads);
+/* gadgets/glv.rs:87-104 : cols[65243][n] */
+long p2e_oracle_glv_mul_witness(const uint8_t *px, const uint8_t *py, const uint8_t *k, uint64_t *cols,
+                                size_t n, size_t ld, uint8_t *err, uint8_t *flags, int nthreads);
+
+/* constants computed at init (for tests): rando = keccak256(0u64 LE) as LE scalar * G */
+void p2e_oracle_rando(uint8_t x32[32], uint8_t y32[32]);
+int p2e_oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
