@@ -1,0 +1,138 @@
+/* p2e -- MI355X-native batch witness generation for plonky2's secp256k1 ECDSA gadget.
+ *
+ * C ABI of libp2e_hip.so.  These entry points are what a plonky2-ecdsa (Rust) build would bind through
+ * `extern "C"` to replace the bodies of its witness generators (see INTEGRATION.md for the stub).
+ * Each entry point cites the reference interface it replaces; paths are relative to the reference
+ * crate's src/ (Weobe/plonky2-ecdsa).
+ *
+ * DATA LAYOUT
+ *   Goldilocks columns: canonical u64 values (< 2^64 - 2^32 + 1), column-major over the batch:
+ *   element i of column c lives at base[c * ld + i] with ld >= n ("SoA": the 64 lanes of a wavefront
+ *   are 64 consecutive batch elements, every access is one coalesced 512-byte transaction).
+ *   A non-native value is 9 consecutive columns of 29-bit limbs, least significant first
+ *   (gadgets/nonnative.rs:32 BITS = 29, gates/mul_nonnative.rs:37-39 num_limbs = 9).
+ *   256-bit inputs of the fused entry points are packed 32-byte little-endian, element i at +32*i.
+ *
+ * MEMORY
+ *   All data pointers are DEVICE pointers (hipMalloc / torch tensors) unless the context was created
+ *   with P2E_CTX_HOST_POINTERS, in which case they are host pointers and the library stages them
+ *   through its own device buffers (PCIe-inclusive; never the benchmarked configuration).
+ *   The caller owns every buffer; the library owns only the p2e_ctx (stream, scratch, constant tables).
+ *
+ * ERRORS
+ *   Return value: < 0 API misuse / HIP failure (p2e_last_error() has the text); >= 0 number of batch
+ *   elements whose err byte is non-zero.  err[i] is a bit mask of P2E_ERR_* -- the conditions under
+ *   which the reference generator panics.  Outputs of a flagged element are unspecified.
+ *   Nothing ever unwinds or aborts across this boundary.
+ *
+ * THREADING  A p2e_ctx is not thread-safe: one context per (host thread, device).  Calls are
+ *   synchronous on return unless P2E_CTX_ASYNC is set (then p2e_sync() completes them and returns the
+ *   flagged-element count of the last call).
+ */
+#ifndef P2E_H
+#define P2E_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2E_FIELD_BASE 0   /* plonky2 Secp256K1Base   (point coordinates)      */
+#define P2E_FIELD_SCALAR 1 /* plonky2 Secp256K1Scalar (msg, r, s, u1, u2, k1, k2) */
+
+/* per-element error bits */
+#define P2E_ERR_LIMB_RANGE 1       /* limb >= 2^29: gates/mul_nonnative.rs:262,271,275-276; biguint.rs:456,473 */
+#define P2E_ERR_VALUE_GE_2_256 2   /* from_noncanonical_biguint panics (template field/p256_base.rs:121-130)  */
+#define P2E_ERR_INVERSE_OF_ZERO 4  /* gadgets/nonnative.rs:863 inverse() of zero                               */
+#define P2E_ERR_CARRY_RANGE 8      /* gates/mul_nonnative.rs:527 carry not < 2^34                              */
+#define P2E_ERR_QUOTIENT_RANGE 16  /* x*y/m does not fit the gate's nine q wires (x, y far above the modulus)  */
+
+/* status codes (negative returns) */
+#define P2E_E_INVALID (-1)   /* null pointer, ld < n, bad field id ...      */
+#define P2E_E_HIP (-2)       /* a HIP call failed                             */
+#define P2E_E_NO_DEVICE (-3) /* no gfx950 device / extension not usable       */
+#define P2E_E_NOMEM (-4)
+
+/* context flags */
+#define P2E_CTX_HOST_POINTERS 1u
+#define P2E_CTX_ASYNC 2u
+
+#define P2E_VERIFY_COLS 82615  /* hot-path generator outputs of one verify_secp256k1_message_circuit */
+#define P2E_GLV_MUL_COLS 65243 /* ... of one glv_mul                                                 */
+
+typedef struct p2e_ctx p2e_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+/* `stream`: a hipStream_t to run on (e.g. torch's current stream), or NULL for a library-owned one. */
+int p2e_ctx_create(int device, unsigned flags, void *stream, p2e_ctx **out);
+void p2e_ctx_destroy(p2e_ctx *ctx);
+int p2e_sync(p2e_ctx *ctx);
+const char *p2e_last_error(void);
+/* bytes of device scratch the fused entry points need for a batch of n (allocated lazily, kept) */
+size_t p2e_scratch_bytes(int program /*0 verify, 1 glv_mul*/, size_t n);
+/* milliseconds of the last call per pipeline phase, measured with hipEvents on the context's stream:
+ * out[0..4] = scalar, chains, batch-inverse, expand, total.  Returns the number written. */
+int p2e_last_phase_ms(p2e_ctx *ctx, float *out, int cap);
+
+/* ---- single generators (one reference run_once body each) ----------------------------------------- */
+/* MulNonnativeGenerator::run_once gates/mul_nonnative.rs:249-324 followed by
+ * CheckSumGenerator::run_once :513-531.  x, y: the gate's 9+9 input wires.  Outputs in gate wire
+ * order (:41-59, :384-390): r[9], q[9], check_sum[17], then b[16] of the CheckSumGate row. */
+long p2e_mul_witness_batch(p2e_ctx *ctx, int field, const uint64_t *x, const uint64_t *y, uint64_t *r,
+                           uint64_t *q, uint64_t *check_sum, uint64_t *b, size_t n, size_t ld, uint8_t *err);
+/* CheckSumGenerator::run_once alone on arbitrary a[17] (true Goldilocks division by 2^29). */
+long p2e_checksum_witness_batch(p2e_ctx *ctx, const uint64_t *a, uint64_t *b, size_t n, size_t ld,
+                                uint8_t *err);
+/* NonNativeAdditionGenerator::run_once gadgets/nonnative.rs:626-645: sum[9], overflow. */
+long p2e_add_witness_batch(p2e_ctx *ctx, int field, const uint64_t *a, const uint64_t *b, uint64_t *sum,
+                           uint64_t *overflow, size_t n, size_t ld, uint8_t *err);
+/* NonNativeSubtractionGenerator::run_once gadgets/nonnative.rs:792-810: diff[9], overflow. */
+long p2e_sub_witness_batch(p2e_ctx *ctx, int field, const uint64_t *a, const uint64_t *b, uint64_t *diff,
+                           uint64_t *overflow, size_t n, size_t ld, uint8_t *err);
+/* NonNativeMultipleAddsGenerator::run_once gadgets/nonnative.rs:696-728: summands[k][9][ld], 1 <= k <= 8. */
+long p2e_add_many_witness_batch(p2e_ctx *ctx, int field, const uint64_t *summands, int k, uint64_t *sum,
+                                uint64_t *overflow, size_t n, size_t ld, uint8_t *err);
+/* NonNativeInverseGenerator::run_once gadgets/nonnative.rs:857-872: inv[9], div[9]. */
+long p2e_inv_witness_batch(p2e_ctx *ctx, int field, const uint64_t *x, uint64_t *inv, uint64_t *div, size_t n,
+                           size_t ld, uint8_t *err);
+/* GLVDecompositionGenerator::run_once gadgets/glv.rs:128-142 (curve/glv.rs:39-77): k1[5], k2[5], signs. */
+long p2e_glv_decompose_batch(p2e_ctx *ctx, const uint64_t *k, uint64_t *k1, uint64_t *k2, uint64_t *k1_neg,
+                             uint64_t *k2_neg, size_t n, size_t ld, uint8_t *err);
+/* set_biguint_target gadgets/biguint.rs:454-463 (convert_base :27-51): packed[n][32] -> limbs[9][ld]. */
+long p2e_limb_split(p2e_ctx *ctx, const uint8_t *packed, uint64_t *limbs, size_t n, size_t ld);
+/* get_biguint_target gadgets/biguint.rs:444-452: limbs[9][ld] -> packed[n][32]. */
+long p2e_limb_pack(p2e_ctx *ctx, const uint64_t *limbs, uint8_t *packed, size_t n, size_t ld, uint8_t *err);
+
+/* ---- fused schedules ------------------------------------------------------------------------------ */
+/* Every hot-path generator output of verify_secp256k1_message_circuit (gadgets/ecdsa.rs:30-53) for n
+ * signatures: cols[P2E_VERIFY_COLS][ld], generator registration order (p2e_schedule_describe).
+ * valid[i] (nullable) = 1 iff the three connect constraints hold (curve_assert_valid, GLV
+ * reconstruction, r == x), i.e. the signature verifies. */
+long p2e_ecdsa_verify_witness_batch(p2e_ctx *ctx, const uint8_t *msg32, const uint8_t *r32, const uint8_t *s32,
+                                    const uint8_t *pkx32, const uint8_t *pky32, uint64_t *cols, size_t n,
+                                    size_t ld, uint8_t *err, uint8_t *valid);
+/* glv_mul(p, k) gadgets/glv.rs:87-104: cols[P2E_GLV_MUL_COLS][ld]. */
+long p2e_glv_mul_witness_batch(p2e_ctx *ctx, const uint8_t *px32, const uint8_t *py32, const uint8_t *k32,
+                               uint64_t *cols, size_t n, size_t ld, uint8_t *err, uint8_t *valid);
+
+/* ---- schedule description (column -> generator map, host only, no GPU needed) ---------------------- */
+typedef struct p2e_gen_desc {
+    int32_t kind;  /* 0 add, 1 sub, 2 add_many, 3 mul(+checksum), 4 inv, 5 glv_decomposition */
+    int32_t field; /* P2E_FIELD_* */
+    uint32_t first_col, num_cols;
+    char label[48]; /* gadget path, e.g. "glv_mul/msm/digit72" */
+} p2e_gen_desc;
+/* program 0 = verify circuit, 1 = glv_mul.  Writes up to cap entries; returns the total count. */
+long p2e_schedule_describe(int program, p2e_gen_desc *out, size_t cap);
+long p2e_schedule_num_cols(int program);
+
+/* ---- synthetic inputs (host only): valid signatures per curve/ecdsa.rs:25-40 sign_message with
+ * sk, msg, nonce drawn from splitmix64(seed, i).  Host buffers of n*32 bytes each. -------------------- */
+int p2e_synth_signatures(uint64_t seed, size_t first, size_t n, uint8_t *msg32, uint8_t *r32, uint8_t *s32,
+                         uint8_t *pkx32, uint8_t *pky32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2E_H */

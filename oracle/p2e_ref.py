@@ -726,6 +726,11 @@ class SplitMix64:
                 return v
 
 
+def synth_signature_at(seed, index):
+    """Signature `index` of the synthetic batch `seed` (same stream as p2e_synth_signatures)."""
+    return synth_signature(SplitMix64((seed ^ (0x9E3779B97F4A7C15 * (index + 1))) & _M64))
+
+
 def synth_signature(rng):
     """(msg, r, s, pkx, pky) of a valid signature; sk, msg, nonce uniform in [1, n)."""
     while True:

@@ -1,0 +1,277 @@
+"""plonky2-ecdsa_amd: MI355X-native batch witness generation for plonky2's secp256k1 ECDSA gadget.
+
+Python host side of the C ABI in ``include/p2e.h`` (``libp2e_hip.so``, hand-written HIP for gfx950).
+The names mirror the reference crate's generator / gadget interface for this path
+(Weobe/plonky2-ecdsa: ``MulNonnativeGenerator``, ``NonNative{Addition,Subtraction,MultipleAdds,
+Inverse}Generator``, ``GLVDecompositionGenerator``, ``glv_mul``, ``verify_secp256k1_message_circuit``),
+with batches instead of single targets:
+
+* Goldilocks columns are ``(num_cols, n)`` uint64 arrays / tensors, column-major over the batch.
+* 256-bit inputs are ``(n, 32)`` uint8 little-endian.
+
+There is NO CPU fallback: without the HIP extension and a GPU every compute call raises.
+torch is used only for device memory / streams / torch.distributed plumbing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libp2e_hip.so")
+
+FIELD_BASE = 0    # plonky2 Secp256K1Base
+FIELD_SCALAR = 1  # plonky2 Secp256K1Scalar
+ERR_LIMB_RANGE, ERR_VALUE_GE_2_256, ERR_INVERSE_OF_ZERO, ERR_CARRY_RANGE, ERR_QUOTIENT_RANGE = 1, 2, 4, 8, 16
+CTX_HOST_POINTERS, CTX_ASYNC = 1, 2
+VERIFY_COLS = 82615
+GLV_MUL_COLS = 65243
+PROGRAM_VERIFY, PROGRAM_GLV_MUL = 0, 1
+
+# every symbol include/p2e.h declares
+EXPORTS = (
+    "p2e_ctx_create", "p2e_ctx_destroy", "p2e_sync", "p2e_last_error", "p2e_scratch_bytes", "p2e_last_phase_ms",
+    "p2e_mul_witness_batch", "p2e_checksum_witness_batch", "p2e_add_witness_batch", "p2e_sub_witness_batch",
+    "p2e_add_many_witness_batch", "p2e_inv_witness_batch", "p2e_glv_decompose_batch", "p2e_limb_split",
+    "p2e_limb_pack", "p2e_ecdsa_verify_witness_batch", "p2e_glv_mul_witness_batch", "p2e_schedule_describe",
+    "p2e_schedule_num_cols", "p2e_synth_signatures",
+)
+
+
+class P2EError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc", "p2e_hip.hip")
+    deps = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    deps.append(os.path.join(_ROOT, "include", "p2e.h"))
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp",
+           "-o", LIB_PATH, src]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+class _GenDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("field", C.c_int32), ("first_col", C.c_uint32), ("num_cols", C.c_uint32),
+                ("label", C.c_char * 48)]
+
+
+def lib():
+    """Load libp2e_hip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise P2EError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(_lib, name)  # AttributeError if a declared symbol is not exported
+        _lib.p2e_last_error.restype = C.c_char_p
+        _lib.p2e_scratch_bytes.restype = C.c_size_t
+        _lib.p2e_scratch_bytes.argtypes = [C.c_int, C.c_size_t]
+        for name in EXPORTS:
+            if name.endswith("_batch") or name in ("p2e_limb_split", "p2e_limb_pack", "p2e_schedule_describe",
+                                                   "p2e_schedule_num_cols"):
+                getattr(_lib, name).restype = C.c_long
+    return _lib
+
+
+def _ptr(a):
+    """device pointer of a torch tensor / host pointer of a numpy array / None"""
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a.data_ptr())
+
+
+def schedule_describe(program: int = PROGRAM_VERIFY):
+    """Column map: list of (kind, field, first_col, num_cols, label) in generator registration order."""
+    L = lib()
+    n = L.p2e_schedule_describe(C.c_int(program), None, C.c_size_t(0))
+    arr = (_GenDesc * n)()
+    L.p2e_schedule_describe(C.c_int(program), arr, C.c_size_t(n))
+    kinds = ("add", "sub", "add_many", "mul", "inv", "glv")
+    return [(kinds[d.kind], d.field, d.first_col, d.num_cols, d.label.decode()) for d in arr]
+
+
+def schedule_num_cols(program: int = PROGRAM_VERIFY) -> int:
+    return int(lib().p2e_schedule_num_cols(C.c_int(program)))
+
+
+def synth_signatures(seed: int, n: int, first: int = 0):
+    """Valid secp256k1 signatures (msg, r, s, pk.x, pk.y) as five (n, 32) uint8 arrays (host)."""
+    out = [np.zeros((n, 32), dtype=np.uint8) for _ in range(5)]
+    rc = lib().p2e_synth_signatures(C.c_uint64(seed), C.c_size_t(first), C.c_size_t(n), *[_ptr(a) for a in out])
+    if rc:
+        raise P2EError("p2e_synth_signatures failed")
+    return out
+
+
+class Context:
+    """One p2e_ctx: one per (host thread, device).
+
+    ``host_pointers=True`` makes every entry point take numpy arrays (staged through the library's own
+    device buffers: convenient for tests, PCIe-inclusive, never benchmarked).  Otherwise arguments are
+    torch CUDA tensors and the context runs on ``stream`` (default: torch's current stream)."""
+
+    def __init__(self, device: int = 0, host_pointers: bool = False, stream=None, asynchronous: bool = False):
+        L = lib()
+        self._L = L
+        self.host_pointers = host_pointers
+        flags = (CTX_HOST_POINTERS if host_pointers else 0) | (CTX_ASYNC if asynchronous else 0)
+        if stream is None and not host_pointers:
+            import torch
+            stream = torch.cuda.current_stream(device).cuda_stream
+        h = C.c_void_p()
+        rc = L.p2e_ctx_create(C.c_int(device), C.c_uint(flags), C.c_void_p(stream or 0), C.byref(h))
+        if rc != 0:
+            raise P2EError(f"p2e_ctx_create failed ({rc}): {L.p2e_last_error().decode()}")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.p2e_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise P2EError(f"p2e call failed ({rc}): {self._L.p2e_last_error().decode()}")
+        return int(rc)
+
+    def sync(self):
+        return self._check(self._L.p2e_sync(self._h))
+
+    def last_phase_ms(self):
+        buf = (C.c_float * 5)()
+        self._L.p2e_last_phase_ms(self._h, buf, C.c_int(5))
+        return dict(zip(("scalar", "chains", "batch_inv", "expand", "total"), [float(x) for x in buf]))
+
+    # ---- allocation helpers -------------------------------------------------------------------------
+    def _cols(self, k, n):
+        if self.host_pointers:
+            return np.zeros((k, n), dtype=np.uint64)
+        import torch
+        return torch.empty((k, n), dtype=torch.int64, device=f"cuda:{self.device}")
+
+    def _vec(self, n, dtype=np.uint64):
+        if self.host_pointers:
+            return np.zeros(n, dtype=dtype)
+        import torch
+        td = {np.uint64: torch.int64, np.uint8: torch.uint8}[dtype]
+        return torch.empty(n, dtype=td, device=f"cuda:{self.device}")
+
+    @staticmethod
+    def _shape(a):
+        return tuple(a.shape)
+
+    # ---- single generators ---------------------------------------------------------------------------
+    def mul_witness_batch(self, field, x, y):
+        """MulNonnativeGenerator + CheckSumGenerator (gates/mul_nonnative.rs:249-324, :513-531)."""
+        n = self._shape(x)[1]
+        r, q, cs, b, err = self._cols(9, n), self._cols(9, n), self._cols(17, n), self._cols(16, n), self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_mul_witness_batch(self._h, C.c_int(field), _ptr(x), _ptr(y), _ptr(r), _ptr(q),
+                                                        _ptr(cs), _ptr(b), C.c_size_t(n), C.c_size_t(n), _ptr(err)))
+        return r, q, cs, b, err, bad
+
+    def checksum_witness_batch(self, a):
+        n = self._shape(a)[1]
+        b, err = self._cols(16, n), self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_checksum_witness_batch(self._h, _ptr(a), _ptr(b), C.c_size_t(n), C.c_size_t(n), _ptr(err)))
+        return b, err, bad
+
+    def _binop(self, fn, field, a, b):
+        n = self._shape(a)[1]
+        out, ov, err = self._cols(9, n), self._vec(n), self._vec(n, np.uint8)
+        bad = self._check(fn(self._h, C.c_int(field), _ptr(a), _ptr(b), _ptr(out), _ptr(ov), C.c_size_t(n),
+                             C.c_size_t(n), _ptr(err)))
+        return out, ov, err, bad
+
+    def add_witness_batch(self, field, a, b):
+        """NonNativeAdditionGenerator (gadgets/nonnative.rs:626-645)."""
+        return self._binop(self._L.p2e_add_witness_batch, field, a, b)
+
+    def sub_witness_batch(self, field, a, b):
+        """NonNativeSubtractionGenerator (gadgets/nonnative.rs:792-810)."""
+        return self._binop(self._L.p2e_sub_witness_batch, field, a, b)
+
+    def add_many_witness_batch(self, field, summands):
+        """NonNativeMultipleAddsGenerator (gadgets/nonnative.rs:696-728); summands (k, 9, n)."""
+        k, _, n = self._shape(summands)
+        out, ov, err = self._cols(9, n), self._vec(n), self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_add_many_witness_batch(self._h, C.c_int(field), _ptr(summands), C.c_int(k),
+                                                             _ptr(out), _ptr(ov), C.c_size_t(n), C.c_size_t(n), _ptr(err)))
+        return out, ov, err, bad
+
+    def inv_witness_batch(self, field, x):
+        """NonNativeInverseGenerator (gadgets/nonnative.rs:857-872)."""
+        n = self._shape(x)[1]
+        inv, div, err = self._cols(9, n), self._cols(9, n), self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_inv_witness_batch(self._h, C.c_int(field), _ptr(x), _ptr(inv), _ptr(div),
+                                                        C.c_size_t(n), C.c_size_t(n), _ptr(err)))
+        return inv, div, err, bad
+
+    def glv_decompose_batch(self, k):
+        """GLVDecompositionGenerator (gadgets/glv.rs:128-142)."""
+        n = self._shape(k)[1]
+        k1, k2, n1, n2, err = self._cols(5, n), self._cols(5, n), self._vec(n), self._vec(n), self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_glv_decompose_batch(self._h, _ptr(k), _ptr(k1), _ptr(k2), _ptr(n1), _ptr(n2),
+                                                          C.c_size_t(n), C.c_size_t(n), _ptr(err)))
+        return k1, k2, n1, n2, err, bad
+
+    def limb_split(self, packed, out=None):
+        """set_biguint_target (gadgets/biguint.rs:454-463): (n, 32) uint8 -> (9, n) limb columns."""
+        n = self._shape(packed)[0]
+        limbs = out if out is not None else self._cols(9, n)
+        self._check(self._L.p2e_limb_split(self._h, _ptr(packed), _ptr(limbs), C.c_size_t(n), C.c_size_t(self._shape(limbs)[1])))
+        return limbs
+
+    def limb_pack(self, limbs):
+        """get_biguint_target (gadgets/biguint.rs:444-452): (9, n) limb columns -> (n, 32) uint8."""
+        n = self._shape(limbs)[1]
+        if self.host_pointers:
+            packed = np.zeros((n, 32), dtype=np.uint8)
+        else:
+            import torch
+            packed = torch.empty((n, 32), dtype=torch.uint8, device=f"cuda:{self.device}")
+        err = self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_limb_pack(self._h, _ptr(limbs), _ptr(packed), C.c_size_t(n), C.c_size_t(n), _ptr(err)))
+        return packed, err, bad
+
+    # ---- fused schedules -----------------------------------------------------------------------------
+    def ecdsa_verify_witness_batch(self, msg, r, s, pkx, pky, cols=None, err=None, valid=None):
+        """verify_secp256k1_message_circuit (gadgets/ecdsa.rs:30-53): (82615, n) Goldilocks columns."""
+        n = self._shape(msg)[0]
+        cols = cols if cols is not None else self._cols(VERIFY_COLS, n)
+        err = err if err is not None else self._vec(n, np.uint8)
+        valid = valid if valid is not None else self._vec(n, np.uint8)
+        ld = self._shape(cols)[1]
+        bad = self._check(self._L.p2e_ecdsa_verify_witness_batch(self._h, _ptr(msg), _ptr(r), _ptr(s), _ptr(pkx), _ptr(pky),
+                                                                 _ptr(cols), C.c_size_t(n), C.c_size_t(ld), _ptr(err), _ptr(valid)))
+        return cols, err, valid, bad
+
+    def glv_mul_witness_batch(self, px, py, k, cols=None, err=None, valid=None):
+        """glv_mul (gadgets/glv.rs:87-104): (65243, n) Goldilocks columns."""
+        n = self._shape(px)[0]
+        cols = cols if cols is not None else self._cols(GLV_MUL_COLS, n)
+        err = err if err is not None else self._vec(n, np.uint8)
+        valid = valid if valid is not None else self._vec(n, np.uint8)
+        ld = self._shape(cols)[1]
+        bad = self._check(self._L.p2e_glv_mul_witness_batch(self._h, _ptr(px), _ptr(py), _ptr(k), _ptr(cols),
+                                                            C.c_size_t(n), C.c_size_t(ld), _ptr(err), _ptr(valid)))
+        return cols, err, valid, bad

@@ -1,0 +1,435 @@
+// 256-bit prime-field arithmetic for secp256k1 (base field p and scalar field n), written for the
+// CDNA4 VALU: 8 x 32-bit limbs per value so every partial product is one v_mad_u64_u32, both moduli
+// are of the form 2^256 - C so reduction is a short "fold the high half times C" chain (C = 2^32+977
+// for p, a 129-bit constant for n) that also yields the exact integer quotient the plonky2
+// MulNonnative / Inverse witness generators need.  No MFMA: integer carry chains.
+//
+// Everything here is __host__ __device__: the same code builds the constant tables on the host at
+// context-create time and is exercised by the CPU emulation harness under tests/emu (test-only).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define P2E_HD __host__ __device__ __forceinline__
+#define P2E_HD_NOINLINE __host__ __device__ __noinline__
+#define P2E_UNROLL _Pragma("unroll")
+#else
+#define P2E_HD inline
+#define P2E_HD_NOINLINE inline
+#define P2E_UNROLL
+#endif
+
+namespace p2e {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int64_t i64;
+
+struct alignas(16) U256 {
+    u32 w[8];
+};
+
+constexpr int BITS = 29;   // reference gadgets/nonnative.rs:32
+constexpr int NL = 9;      // ceil(256/29), reference gates/mul_nonnative.rs:37-39
+constexpr u32 MASK29 = (1u << BITS) - 1;
+constexpr u64 P_GL = 0xFFFFFFFF00000001ull;  // Goldilocks
+
+// error bits, mirrored in include/p2e.h
+constexpr uint8_t ERR_LIMB_RANGE = 1, ERR_VALUE_GE_2_256 = 2, ERR_INVERSE_OF_ZERO = 4, ERR_CARRY_RANGE = 8,
+                  ERR_QUOTIENT_RANGE = 16;
+
+// ------------------------------------------------------------------------------------------------
+// moduli: m = 2^256 - C
+// ------------------------------------------------------------------------------------------------
+struct ModP {  // Secp256K1Base
+    static constexpr int NC = 2;
+    static constexpr bool kFourFolds = false;
+    P2E_HD static u32 c(int i) {
+        constexpr u32 v[2] = {0x000003D1u, 0x00000001u};
+        return v[i];
+    }
+    P2E_HD static u32 m(int i) {
+        constexpr u32 v[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu,
+                              0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        return v[i];
+    }
+    // 29-bit limbs of m (convert_base(m, 32, 29))
+    P2E_HD static u32 m29(int i) {
+        constexpr u32 v[9] = {0x1FFFFC2Fu, 0x1FFFFFF7u, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu,
+                              0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x00FFFFFFu};
+        return v[i];
+    }
+};
+struct ModN {  // Secp256K1Scalar
+    static constexpr int NC = 5;
+    static constexpr bool kFourFolds = true;
+    P2E_HD static u32 c(int i) {
+        constexpr u32 v[5] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 0x00000001u};
+        return v[i];
+    }
+    P2E_HD static u32 m(int i) {
+        constexpr u32 v[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
+                              0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        return v[i];
+    }
+    P2E_HD static u32 m29(int i) {
+        constexpr u32 v[9] = {0x10364141u, 0x1E92F466u, 0x12280EEFu, 0x1DB9CD5Eu, 0x1FFFEBAAu,
+                              0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x00FFFFFFu};
+        return v[i];
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// multi-word helpers (fully unrolled so the arrays live in VGPRs)
+// ------------------------------------------------------------------------------------------------
+template <int NA, int NB>
+P2E_HD void mul_wide(const u32* a, const u32* b, u32* r) {  // r: NA+NB words
+    P2E_UNROLL
+    for (int i = 0; i < NA + NB; i++) r[i] = 0;
+    P2E_UNROLL
+    for (int i = 0; i < NA; i++) {
+        u64 c = 0;
+        P2E_UNROLL
+        for (int j = 0; j < NB; j++) {
+            u64 t = (u64)a[i] * b[j] + r[i + j] + c;
+            r[i + j] = (u32)t;
+            c = t >> 32;
+        }
+        r[i + NB] = (u32)c;
+    }
+}
+
+template <int N>
+P2E_HD u32 add_n(u32* r, const u32* a, const u32* b) {
+    u64 c = 0;
+    P2E_UNROLL
+    for (int i = 0; i < N; i++) {
+        c += (u64)a[i] + b[i];
+        r[i] = (u32)c;
+        c >>= 32;
+    }
+    return (u32)c;
+}
+template <int N>
+P2E_HD u32 sub_n(u32* r, const u32* a, const u32* b) {  // returns borrow
+    u32 br = 0;
+    P2E_UNROLL
+    for (int i = 0; i < N; i++) {
+        u64 d = (u64)a[i] - b[i] - br;
+        r[i] = (u32)d;
+        br = (u32)(d >> 63);
+    }
+    return br;
+}
+template <int N>
+P2E_HD bool geq_n(const u32* a, const u32* b) {  // a >= b
+    u32 br = 0;
+    P2E_UNROLL
+    for (int i = 0; i < N; i++) {
+        u64 d = (u64)a[i] - b[i] - br;
+        br = (u32)(d >> 63);
+    }
+    return br == 0;
+}
+template <int N>
+P2E_HD bool is_zero_n(const u32* a) {
+    u32 o = 0;
+    P2E_UNROLL
+    for (int i = 0; i < N; i++) o |= a[i];
+    return o == 0;
+}
+template <class MOD>
+P2E_HD bool geq_mod(const u32* a) {
+    u32 br = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) {
+        u64 d = (u64)a[i] - MOD::m(i) - br;
+        br = (u32)(d >> 63);
+    }
+    return br == 0;
+}
+template <class MOD>
+P2E_HD void sub_mod_raw(u32* a) {  // a -= m
+    u32 br = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) {
+        u64 d = (u64)a[i] - MOD::m(i) - br;
+        a[i] = (u32)d;
+        br = (u32)(d >> 63);
+    }
+}
+template <class MOD>
+P2E_HD void add_mod_raw(u32* a) {  // a += m (mod 2^256)
+    u64 c = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) {
+        c += (u64)a[i] + MOD::m(i);
+        a[i] = (u32)c;
+        c >>= 32;
+    }
+}
+
+P2E_HD U256 u256_zero() {
+    U256 r;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) r.w[i] = 0;
+    return r;
+}
+P2E_HD U256 u256_small(u32 v) {
+    U256 r = u256_zero();
+    r.w[0] = v;
+    return r;
+}
+P2E_HD bool u256_eq(const U256& a, const U256& b) {
+    u32 o = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) o |= a.w[i] ^ b.w[i];
+    return o == 0;
+}
+P2E_HD bool u256_is_zero(const U256& a) { return is_zero_n<8>(a.w); }
+
+// one fold step: (hi[NH], lo[8]) -> t = hi*C + lo ; lo = t mod 2^256 ; hi_out[NHO] = t >> 256 ;
+// q += (t >> 256)
+template <class MOD, int NH, int NHO, bool WANT_Q>
+P2E_HD void fold_step(const u32* hi, u32* lo, u32* hi_out, u32* q /*9 words*/) {
+    constexpr int NT = NH + MOD::NC + 1;
+    u32 t[NT];
+    u32 cw[MOD::NC];
+    P2E_UNROLL
+    for (int i = 0; i < MOD::NC; i++) cw[i] = MOD::c(i);
+    mul_wide<NH, MOD::NC>(hi, cw, t);
+    t[NT - 1] = 0;
+    u64 c = 0;
+    P2E_UNROLL
+    for (int i = 0; i < NT; i++) {
+        c += (u64)t[i] + (i < 8 ? lo[i] : 0u);
+        t[i] = (u32)c;
+        c >>= 32;
+    }
+    if (NT < 8) {  // NH + NC + 1 < 8 : remaining low words keep lo + carry
+        P2E_UNROLL
+        for (int i = NT; i < 8; i++) {
+            c += (u64)lo[i];
+            lo[i] = (u32)c;
+            c >>= 32;
+        }
+        P2E_UNROLL
+        for (int i = 0; i < NT; i++) lo[i] = t[i];
+        P2E_UNROLL
+        for (int k = 0; k < NHO; k++) hi_out[k] = k == 0 ? (u32)c : 0u;
+    } else {
+        P2E_UNROLL
+        for (int i = 0; i < 8; i++) lo[i] = t[i];
+        P2E_UNROLL
+        for (int k = 0; k < NHO; k++) hi_out[k] = (8 + k < NT) ? t[8 + k] : 0u;
+    }
+    if (WANT_Q) {
+        u64 cq = 0;
+        P2E_UNROLL
+        for (int i = 0; i < 9; i++) {
+            cq += (u64)q[i] + (i < NHO ? hi_out[i] : 0u);
+            q[i] = (u32)cq;
+            cq >>= 32;
+        }
+    }
+}
+
+// prod = hi:lo with NH high words.  Returns canonical r = prod mod m and (optionally) the exact
+// integer quotient q = floor(prod / m) in 9 words.  Fold schedule (hi word counts): p: NH,2,1 ;
+// n: NH,5,1,1 -- bounds derived in DESIGN.md "Field arithmetic".
+template <class MOD, int NH, bool WANT_Q>
+P2E_HD void reduce_wide(const u32* prod /*8+NH*/, u32* r /*8*/, u32* q /*9 or null*/) {
+    u32 lo[8];
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) lo[i] = prod[i];
+    if (WANT_Q) {
+        P2E_UNROLL
+        for (int i = 0; i < 9; i++) q[i] = i < NH ? prod[8 + i] : 0u;
+    }
+    u32 h1[MOD::NC];
+    fold_step<MOD, NH, MOD::NC, WANT_Q>(prod + 8, lo, h1, q);
+    u32 h2[1];
+    fold_step<MOD, MOD::NC, 1, WANT_Q>(h1, lo, h2, q);
+    u32 h3[1];
+    fold_step<MOD, 1, 1, WANT_Q>(h2, lo, h3, q);
+    if (MOD::kFourFolds) {
+        u32 h4[1];
+        fold_step<MOD, 1, 1, WANT_Q>(h3, lo, h4, q);
+    }
+    if (geq_mod<MOD>(lo)) {
+        sub_mod_raw<MOD>(lo);
+        if (WANT_Q) {
+            u64 cq = 1;
+            P2E_UNROLL
+            for (int i = 0; i < 9; i++) {
+                cq += q[i];
+                q[i] = (u32)cq;
+                cq >>= 32;
+            }
+        }
+    }
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) r[i] = lo[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// field ops on canonical values
+// ------------------------------------------------------------------------------------------------
+// The multiply is the one function that is NOT force-inlined on the device: the Jacobian chains and
+// the Fermat ladders call it hundreds of times and an inlined copy is ~400 instructions, which would
+// blow the instruction cache.  Arguments/results travel by value in VGPRs.
+template <class MOD>
+P2E_HD_NOINLINE U256 fe_mul_call(U256 a, U256 b) {
+    u32 prod[16];
+    mul_wide<8, 8>(a.w, b.w, prod);
+    U256 r;
+    reduce_wide<MOD, 8, false>(prod, r.w, nullptr);
+    return r;
+}
+template <class MOD>
+P2E_HD U256 fe_mul(const U256& a, const U256& b) {
+    return fe_mul_call<MOD>(a, b);
+}
+template <class MOD>
+P2E_HD U256 fe_sqr(const U256& a) {
+    return fe_mul<MOD>(a, a);
+}
+template <class MOD>
+P2E_HD U256 fe_add(const U256& a, const U256& b) {
+    U256 r;
+    u32 c = add_n<8>(r.w, a.w, b.w);
+    if (c || geq_mod<MOD>(r.w)) sub_mod_raw<MOD>(r.w);
+    return r;
+}
+template <class MOD>
+P2E_HD U256 fe_sub(const U256& a, const U256& b) {
+    U256 r;
+    if (sub_n<8>(r.w, a.w, b.w)) add_mod_raw<MOD>(r.w);
+    return r;
+}
+template <class MOD>
+P2E_HD U256 fe_neg(const U256& a) {
+    return fe_sub<MOD>(u256_zero(), a);
+}
+template <class MOD>
+P2E_HD U256 fe_dbl(const U256& a) {
+    return fe_add<MOD>(a, a);
+}
+// to_canonical_biguint of the reference's field types: ONE conditional subtraction
+template <class MOD>
+P2E_HD U256 fe_canon(const U256& a) {
+    U256 r = a;
+    if (geq_mod<MOD>(r.w)) sub_mod_raw<MOD>(r.w);
+    return r;
+}
+template <class MOD>
+P2E_HD U256 fe_sqr_n(U256 a, int n) {
+    for (int i = 0; i < n; i++) a = fe_sqr<MOD>(a);
+    return a;
+}
+// a^(p-2) mod p: 255 squarings + 15 multiplications (addition chain over the run structure of p-2)
+P2E_HD U256 fe_inv_p(const U256& a) {
+    U256 x2 = fe_mul<ModP>(fe_sqr<ModP>(a), a);
+    U256 x3 = fe_mul<ModP>(fe_sqr<ModP>(x2), a);
+    U256 x6 = fe_mul<ModP>(fe_sqr_n<ModP>(x3, 3), x3);
+    U256 x9 = fe_mul<ModP>(fe_sqr_n<ModP>(x6, 3), x3);
+    U256 x11 = fe_mul<ModP>(fe_sqr_n<ModP>(x9, 2), x2);
+    U256 x22 = fe_mul<ModP>(fe_sqr_n<ModP>(x11, 11), x11);
+    U256 x44 = fe_mul<ModP>(fe_sqr_n<ModP>(x22, 22), x22);
+    U256 x88 = fe_mul<ModP>(fe_sqr_n<ModP>(x44, 44), x44);
+    U256 x176 = fe_mul<ModP>(fe_sqr_n<ModP>(x88, 88), x88);
+    U256 x220 = fe_mul<ModP>(fe_sqr_n<ModP>(x176, 44), x44);
+    U256 x223 = fe_mul<ModP>(fe_sqr_n<ModP>(x220, 3), x3);
+    U256 t = fe_mul<ModP>(fe_sqr_n<ModP>(x223, 23), x22);
+    t = fe_mul<ModP>(fe_sqr_n<ModP>(t, 5), a);
+    t = fe_mul<ModP>(fe_sqr_n<ModP>(t, 3), x2);
+    t = fe_mul<ModP>(fe_sqr_n<ModP>(t, 2), a);
+    return t;
+}
+// a^(n-2) mod n: plain square-and-multiply.  The exponent is a compile-time constant, so the branch
+// is wave-uniform (no divergence, no table in scratch); it runs once per signature (s^-1).
+P2E_HD U256 fe_inv_n(const U256& a) {
+    U256 acc = a;  // top bit of n-2 is set
+    for (int i = 254; i >= 0; i--) {
+        acc = fe_sqr<ModN>(acc);
+        u32 word = ModN::m(i >> 5);
+        if ((i >> 5) == 0) word -= 2;  // low word of n is 0xD0364141: no borrow
+        if ((word >> (i & 31)) & 1) acc = fe_mul<ModN>(acc, a);
+    }
+    return acc;
+}
+template <class MOD>
+P2E_HD U256 fe_inv(const U256& a);
+template <>
+P2E_HD U256 fe_inv<ModP>(const U256& a) {
+    return fe_inv_p(a);
+}
+template <>
+P2E_HD U256 fe_inv<ModN>(const U256& a) {
+    return fe_inv_n(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 29-bit limb split / pack (reference gadgets/biguint.rs:27-51 convert_base, :454-463 set_biguint_target)
+// ------------------------------------------------------------------------------------------------
+// limb k of an NW-word value
+template <int NW>
+P2E_HD u32 limb29(const u32* w, int k) {
+    int bit = BITS * k;
+    int wi = bit >> 5, sh = bit & 31;
+    if (wi >= NW) return 0;
+    u64 lo = w[wi];
+    u64 hi = (wi + 1 < NW) ? w[wi + 1] : 0u;
+    return (u32)(((lo | (hi << 32)) >> sh)) & MASK29;
+}
+P2E_HD void split29(const U256& a, u32* l /*9*/) {
+    P2E_UNROLL
+    for (int k = 0; k < NL; k++) l[k] = limb29<8>(a.w, k);
+}
+// 9 limbs (each < 2^29) -> 9 words (261 bits)
+P2E_HD void pack29_wide(const u32* l /*9*/, u32* w /*9*/) {
+    P2E_UNROLL
+    for (int i = 0; i < 9; i++) w[i] = 0;
+    P2E_UNROLL
+    for (int k = 0; k < NL; k++) {
+        int bit = BITS * k;
+        int wi = bit >> 5, sh = bit & 31;
+        u64 v = (u64)l[k] << sh;
+        w[wi] |= (u32)v;
+        if (wi + 1 < 9) w[wi + 1] |= (u32)(v >> 32);
+    }
+}
+
+// Goldilocks-canonical encoding of a signed integer |v| < 2^63
+P2E_HD u64 gl_from_i64(i64 v) { return v >= 0 ? (u64)v : (u64)v + P_GL; }
+
+// Goldilocks multiply (only used by the standalone CheckSum entry point, which must do a true field
+// division for arbitrary inputs; the fused mul path never needs it)
+P2E_HD u64 gl_reduce128(u64 lo, u64 hi) {
+    u64 hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
+    // x = lo + hl*2^64 + hh*2^96 ; 2^64 = 2^32 - 1, 2^96 = -1 (mod p)
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= 0xFFFFFFFFull;  // borrow: add p (== subtract 2^32-1 mod 2^64)
+    u64 t1 = hl * 0xFFFFFFFFull;
+    u64 r = t0 + t1;
+    if (r < t1) r += 0xFFFFFFFFull;  // carry: subtract p (== add 2^32-1 mod 2^64)
+    if (r >= P_GL) r -= P_GL;
+    return r;
+}
+P2E_HD u64 gl_mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 lo = a * b;
+    u64 hi = __umul64hi(a, b);
+#else
+    unsigned __int128 p = (unsigned __int128)a * b;
+    u64 lo = (u64)p, hi = (u64)(p >> 64);
+#endif
+    return gl_reduce128(lo, hi);
+}
+P2E_HD u64 gl_add(u64 a, u64 b) {
+    u64 s = a + b;
+    if (s < a || s >= P_GL) s -= P_GL;
+    return s;
+}
+
+}  // namespace p2e

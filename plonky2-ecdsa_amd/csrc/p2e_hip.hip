@@ -1,0 +1,681 @@
+// libp2e_hip.so: gfx950 kernels + the C ABI of include/p2e.h.
+// One process drives one GPU; every entry point enqueues on the context's stream.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/p2e.h"
+#include "consts.hpp"
+#include "pipeline.hpp"
+#include "prims.hpp"
+#include "schedule.hpp"
+
+using namespace p2e;
+
+// ====================================================================================================
+// kernels
+// ====================================================================================================
+constexpr int BS = 256;          // 4 waves per workgroup
+constexpr int BINV_CHUNK = 40;   // curve ops per Montgomery batch (one Fermat ladder each)
+
+__global__ __launch_bounds__(BS) void k_scalar(Program G, Buffers B) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    if (i < B.n) body_scalar(G, B, i);
+}
+__global__ __launch_bounds__(BS) void k_chains(Program G, Buffers B, int first_chain) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    if (i < B.n) body_chain(G, B, i, first_chain + (int)blockIdx.y);
+}
+__global__ __launch_bounds__(BS) void k_batch_inv(Program G, Buffers B) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    int t0 = (int)blockIdx.y * BINV_CHUNK;
+    int t1 = t0 + BINV_CHUNK < G.num_ops ? t0 + BINV_CHUNK : G.num_ops;
+    if (i < B.n) body_batch_inv(G, B, i, t0, t1);
+}
+__global__ __launch_bounds__(BS) void k_expand(Program G, Buffers B) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    if (i < B.n) body_expand(G, B, i, (int)blockIdx.y);
+}
+// err words -> caller's err bytes, valid bytes, flagged count
+__global__ __launch_bounds__(BS) void k_finalize(const u32* err32, const uint8_t* valid8, uint8_t* err_out,
+                                                 uint8_t* valid_out, size_t n, unsigned long long* counter) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        u32 e = err32[i];
+        bad = e != 0;
+        if (err_out) err_out[i] = (uint8_t)e;
+        if (valid_out) valid_out[i] = bad ? 0 : valid8[i];
+    }
+    unsigned long long m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (unsigned long long)__popcll(m));
+}
+
+__device__ __forceinline__ void count_err(uint8_t e, unsigned long long* counter) {
+    unsigned long long m = __ballot(e != 0);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (unsigned long long)__popcll(m));
+}
+template <class MOD>
+__global__ __launch_bounds__(BS) void k_mul(const u64* x, const u64* y, u64* r, u64* q, u64* cs, u64* b, size_t n,
+                                            size_t ld, uint8_t* err, unsigned long long* counter) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    uint8_t e = 0;
+    if (i < n) {
+        e = prim_mul<MOD>(x, y, r, q, cs, b, ld, i);
+        err[i] = e;
+    }
+    count_err(e, counter);
+}
+__global__ __launch_bounds__(BS) void k_checksum(const u64* a, u64* b, size_t n, size_t ld, uint8_t* err,
+                                                 unsigned long long* counter) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    uint8_t e = 0;
+    if (i < n) {
+        e = prim_checksum(a, b, ld, i);
+        err[i] = e;
+    }
+    count_err(e, counter);
+}
+template <class MOD, bool IS_SUB>
+__global__ __launch_bounds__(BS) void k_addsub(const u64* a, const u64* b, u64* out, u64* ov, size_t n, size_t ld,
+                                               uint8_t* err, unsigned long long* counter) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    uint8_t e = 0;
+    if (i < n) {
+        e = prim_addsub<MOD, IS_SUB>(a, b, out, ov, ld, i);
+        err[i] = e;
+    }
+    count_err(e, counter);
+}
+template <class MOD>
+__global__ __launch_bounds__(BS) void k_add_many(const u64* s, int k, u64* out, u64* ov, size_t n, size_t ld,
+                                                 uint8_t* err, unsigned long long* counter) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    uint8_t e = 0;
+    if (i < n) {
+        e = prim_add_many<MOD>(s, k, out, ov, ld, i);
+        err[i] = e;
+    }
+    count_err(e, counter);
+}
+template <class MOD>
+__global__ __launch_bounds__(BS) void k_inv(const u64* x, u64* inv, u64* div, size_t n, size_t ld, uint8_t* err,
+                                            unsigned long long* counter) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    uint8_t e = 0;
+    if (i < n) {
+        e = prim_inv<MOD>(x, inv, div, ld, i);
+        err[i] = e;
+    }
+    count_err(e, counter);
+}
+__global__ __launch_bounds__(BS) void k_glv(const u64* k, u64* k1, u64* k2, u64* n1, u64* n2, size_t n, size_t ld,
+                                            uint8_t* err, unsigned long long* counter) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    uint8_t e = 0;
+    if (i < n) {
+        e = prim_glv(k, k1, k2, n1, n2, ld, i);
+        err[i] = e;
+    }
+    count_err(e, counter);
+}
+// 29-bit limb split: pure streaming, 32 B in + 72 B out per element.  Each lane converts two adjacent
+// elements so that every global access is 16 B per lane (64 B contiguous loads, dwordx4 column stores).
+__global__ __launch_bounds__(BS) void k_split(const uint8_t* packed, u64* limbs, size_t n, size_t ld) {
+    size_t pairs = n >> 1;
+    size_t stride = (size_t)gridDim.x * BS;
+    bool aligned = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(limbs) & 15) == 0);
+    for (size_t p = (size_t)blockIdx.x * BS + threadIdx.x; p < pairs; p += stride) {
+        const uint4* src = reinterpret_cast<const uint4*>(packed + 64 * p);
+        uint4 a0 = src[0], a1 = src[1], b0 = src[2], b1 = src[3];
+        U256 va, vb;
+        va.w[0] = a0.x; va.w[1] = a0.y; va.w[2] = a0.z; va.w[3] = a0.w;
+        va.w[4] = a1.x; va.w[5] = a1.y; va.w[6] = a1.z; va.w[7] = a1.w;
+        vb.w[0] = b0.x; vb.w[1] = b0.y; vb.w[2] = b0.z; vb.w[3] = b0.w;
+        vb.w[4] = b1.x; vb.w[5] = b1.y; vb.w[6] = b1.z; vb.w[7] = b1.w;
+        u32 la[NL], lb[NL];
+        split29(va, la);
+        split29(vb, lb);
+        if (aligned) {
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                uint4 o = make_uint4(la[k], 0u, lb[k], 0u);
+                *reinterpret_cast<uint4*>(limbs + (size_t)k * ld + 2 * p) = o;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                limbs[(size_t)k * ld + 2 * p] = la[k];
+                limbs[(size_t)k * ld + 2 * p + 1] = lb[k];
+            }
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) prim_split(packed, limbs, ld, n - 1);
+}
+__global__ __launch_bounds__(BS) void k_pack(const u64* limbs, uint8_t* packed, size_t n, size_t ld, uint8_t* err,
+                                             unsigned long long* counter) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    uint8_t e = 0;
+    if (i < n) {
+        e = prim_pack(limbs, packed, ld, i);
+        err[i] = e;
+    }
+    count_err(e, counter);
+}
+
+// ====================================================================================================
+// context
+// ====================================================================================================
+static thread_local std::string g_last_error;
+static void set_error(const std::string& s) { g_last_error = s; }
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+            return P2E_E_HIP;                                                                \
+        }                                                                                    \
+    } while (0)
+
+struct DeviceProgram {
+    Program prog;
+    OpDesc* d_ops = nullptr;
+    std::vector<host::GenOp> gens;
+};
+
+struct p2e_ctx {
+    int device = 0;
+    unsigned flags = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Aff* d_cpts = nullptr;
+    Aff* d_fbtab = nullptr;
+    DeviceProgram progs[2];
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    unsigned long long* d_counter = nullptr;
+    unsigned long long* h_counter = nullptr;  // pinned
+    hipEvent_t ev[6] = {};
+    float phase_ms[5] = {0, 0, 0, 0, 0};
+    bool have_phases = false;
+};
+
+static const DeviceProgram& host_program(int program) {
+    static DeviceProgram P[2];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        host::ScheduleBuilder b0;
+        b0.verify_secp256k1_message_circuit();
+        P[0].prog = b0.prog;
+        P[0].gens = b0.gens;
+        host::ScheduleBuilder b1;
+        b1.glv_mul_circuit();
+        P[1].prog = b1.prog;
+        P[1].gens = b1.gens;
+    });
+    return P[program];
+}
+static std::vector<OpDesc> host_ops(int program) {
+    host::ScheduleBuilder b;
+    if (program == 0)
+        b.verify_secp256k1_message_circuit();
+    else
+        b.glv_mul_circuit();
+    return b.ops;
+}
+
+struct ScratchLayout {
+    size_t px, py, pz, pw, pref, dig4, dig2, dyn, err32, valid8, total;
+};
+static ScratchLayout scratch_layout(const Program& G, size_t n) {
+    ScratchLayout L{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    L.px = take((size_t)G.num_slots * n * 32);
+    L.py = take((size_t)G.num_slots * n * 32);
+    L.pz = take((size_t)G.num_ops * n * 32);
+    L.pw = take((size_t)G.num_ops * n * 32);
+    L.pref = take((size_t)G.num_ops * n * 32);
+    L.dig4 = take((size_t)FB_WINDOWS * n);
+    L.dig2 = take((size_t)MSM_DIGITS * n);
+    L.dyn = take((size_t)G.num_cadd * n * 2);
+    L.err32 = take(n * 4);
+    L.valid8 = take(n);
+    L.total = off;
+    return L;
+}
+
+extern "C" const char* p2e_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" size_t p2e_scratch_bytes(int program, size_t n) {
+    if (program < 0 || program > 1) return 0;
+    return scratch_layout(host_program(program).prog, n).total;
+}
+
+extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx** out) {
+    if (!out) return P2E_E_INVALID;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        set_error("no HIP device visible: libp2e_hip needs a gfx950 GPU (there is no CPU fallback)");
+        return P2E_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device index out of range");
+        return P2E_E_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device));
+    p2e_ctx* c = new p2e_ctx();
+    c->device = device;
+    c->flags = flags;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    const host::Consts& C = host::consts();
+    HIP_TRY(hipMalloc(&c->d_cpts, sizeof(Aff) * NUM_CONST_PTS));
+    HIP_TRY(hipMalloc(&c->d_fbtab, sizeof(Aff) * C.fbtab.size()));
+    HIP_TRY(hipMemcpy(c->d_cpts, C.cpts, sizeof(Aff) * NUM_CONST_PTS, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_fbtab, C.fbtab.data(), sizeof(Aff) * C.fbtab.size(), hipMemcpyHostToDevice));
+    for (int p = 0; p < 2; p++) {
+        c->progs[p].prog = host_program(p).prog;
+        std::vector<OpDesc> ops = host_ops(p);
+        HIP_TRY(hipMalloc(&c->progs[p].d_ops, sizeof(OpDesc) * ops.size()));
+        HIP_TRY(hipMemcpy(c->progs[p].d_ops, ops.data(), sizeof(OpDesc) * ops.size(), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&c->d_counter, sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc(&c->h_counter, sizeof(unsigned long long)));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    *out = c;
+    return 0;
+}
+
+extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_cpts);
+    (void)hipFree(c->d_fbtab);
+    for (auto& p : c->progs) (void)hipFree(p.d_ops);
+    (void)hipFree(c->scratch);
+    (void)hipFree(c->d_counter);
+    (void)hipHostFree(c->h_counter);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int p2e_sync(p2e_ctx* c) {
+    if (!c) return P2E_E_INVALID;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->have_phases) {
+        for (int k = 0; k < 4; k++) (void)hipEventElapsedTime(&c->phase_ms[k], c->ev[k], c->ev[k + 1]);
+        (void)hipEventElapsedTime(&c->phase_ms[4], c->ev[0], c->ev[4]);
+    }
+    return (int)*c->h_counter;
+}
+
+extern "C" int p2e_last_phase_ms(p2e_ctx* c, float* out, int cap) {
+    if (!c || !out) return P2E_E_INVALID;
+    int k = cap < 5 ? cap : 5;
+    for (int i = 0; i < k; i++) out[i] = c->phase_ms[i];
+    return k;
+}
+
+static int ensure_scratch(p2e_ctx* c, size_t bytes) {
+    if (bytes <= c->scratch_bytes) return 0;
+    if (c->scratch) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->scratch));
+        c->scratch = nullptr;
+        c->scratch_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&c->scratch, bytes);
+    if (e != hipSuccess) {
+        set_error("scratch allocation failed");
+        return P2E_E_NOMEM;
+    }
+    c->scratch_bytes = bytes;
+    return 0;
+}
+
+// finish a call: fetch the flagged count (synchronously unless the context is async)
+static long finish_call(p2e_ctx* c) {
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        set_error(std::string("kernel launch: ") + hipGetErrorString(le));
+        return P2E_E_HIP;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_counter, c->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    if (c->flags & P2E_CTX_ASYNC) return 0;
+    int r = p2e_sync(c);
+    return r;
+}
+
+// ---- host-pointer staging (slow path, used by ctypes-only callers) ----------------------------------
+struct Staged {
+    p2e_ctx* c;
+    std::vector<void*> dev;
+    struct Out {
+        void* host;
+        void* dev;
+        size_t bytes;
+    };
+    std::vector<Out> outs;
+    bool host;
+    int rc = 0;
+    explicit Staged(p2e_ctx* ctx) : c(ctx), host((ctx->flags & P2E_CTX_HOST_POINTERS) != 0) {}
+    template <class T>
+    const T* in(const T* p, size_t bytes) {
+        if (!host || !p) return p;
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) {
+            rc = P2E_E_NOMEM;
+            return nullptr;
+        }
+        dev.push_back(d);
+        if (hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = P2E_E_HIP;
+        return (const T*)d;
+    }
+    template <class T>
+    T* out(T* p, size_t bytes) {
+        if (!host || !p) return p;
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) {
+            rc = P2E_E_NOMEM;
+            return nullptr;
+        }
+        dev.push_back(d);
+        outs.push_back({p, d, bytes});
+        return (T*)d;
+    }
+    long done(long r) {
+        if (host) {
+            for (auto& o : outs)
+                if (hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) r = P2E_E_HIP;
+            (void)hipStreamSynchronize(c->stream);
+            for (void* d : dev) (void)hipFree(d);
+        }
+        return r;
+    }
+};
+
+static bool bad_common(p2e_ctx* c, size_t n, size_t ld) {
+    if (!c) {
+        set_error("null context");
+        return true;
+    }
+    if (ld < n) {
+        set_error("ld < n");
+        return true;
+    }
+    (void)hipSetDevice(c->device);
+    return false;
+}
+static inline dim3 grid1(size_t n) { return dim3((unsigned)((n + BS - 1) / BS)); }
+#define ZERO_COUNTER(c) HIP_TRY(hipMemsetAsync((c)->d_counter, 0, sizeof(unsigned long long), (c)->stream))
+
+// ====================================================================================================
+// single generators
+// ====================================================================================================
+extern "C" long p2e_mul_witness_batch(p2e_ctx* c, int field, const uint64_t* x, const uint64_t* y, uint64_t* r,
+                                      uint64_t* q, uint64_t* cs, uint64_t* b, size_t n, size_t ld, uint8_t* err) {
+    if (bad_common(c, n, ld) || !x || !y || !r || !q || !cs || !b || !err || (field != 0 && field != 1)) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    Staged S(c);
+    size_t cb = ld * 8;
+    x = S.in(x, 9 * cb);
+    y = S.in(y, 9 * cb);
+    r = S.out(r, 9 * cb);
+    q = S.out(q, 9 * cb);
+    cs = S.out(cs, 17 * cb);
+    b = S.out(b, 16 * cb);
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    if (field == P2E_FIELD_BASE)
+        hipLaunchKernelGGL(k_mul<ModP>, grid1(n), dim3(BS), 0, c->stream, x, y, r, q, cs, b, n, ld, err, c->d_counter);
+    else
+        hipLaunchKernelGGL(k_mul<ModN>, grid1(n), dim3(BS), 0, c->stream, x, y, r, q, cs, b, n, ld, err, c->d_counter);
+    return S.done(finish_call(c));
+}
+extern "C" long p2e_checksum_witness_batch(p2e_ctx* c, const uint64_t* a, uint64_t* b, size_t n, size_t ld, uint8_t* err) {
+    if (bad_common(c, n, ld) || !a || !b || !err) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    Staged S(c);
+    a = S.in(a, 17 * ld * 8);
+    b = S.out(b, 16 * ld * 8);
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    hipLaunchKernelGGL(k_checksum, grid1(n), dim3(BS), 0, c->stream, a, b, n, ld, err, c->d_counter);
+    return S.done(finish_call(c));
+}
+static long addsub(p2e_ctx* c, int field, bool is_sub, const uint64_t* a, const uint64_t* b, uint64_t* out,
+                   uint64_t* ov, size_t n, size_t ld, uint8_t* err) {
+    if (bad_common(c, n, ld) || !a || !b || !out || !ov || !err || (field != 0 && field != 1)) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    Staged S(c);
+    a = S.in(a, 9 * ld * 8);
+    b = S.in(b, 9 * ld * 8);
+    out = S.out(out, 9 * ld * 8);
+    ov = S.out(ov, n * 8);
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    dim3 g = grid1(n), bs(BS);
+    if (field == 0 && !is_sub) hipLaunchKernelGGL((k_addsub<ModP, false>), g, bs, 0, c->stream, a, b, out, ov, n, ld, err, c->d_counter);
+    if (field == 0 && is_sub) hipLaunchKernelGGL((k_addsub<ModP, true>), g, bs, 0, c->stream, a, b, out, ov, n, ld, err, c->d_counter);
+    if (field == 1 && !is_sub) hipLaunchKernelGGL((k_addsub<ModN, false>), g, bs, 0, c->stream, a, b, out, ov, n, ld, err, c->d_counter);
+    if (field == 1 && is_sub) hipLaunchKernelGGL((k_addsub<ModN, true>), g, bs, 0, c->stream, a, b, out, ov, n, ld, err, c->d_counter);
+    return S.done(finish_call(c));
+}
+extern "C" long p2e_add_witness_batch(p2e_ctx* c, int field, const uint64_t* a, const uint64_t* b, uint64_t* sum,
+                                      uint64_t* ov, size_t n, size_t ld, uint8_t* err) {
+    return addsub(c, field, false, a, b, sum, ov, n, ld, err);
+}
+extern "C" long p2e_sub_witness_batch(p2e_ctx* c, int field, const uint64_t* a, const uint64_t* b, uint64_t* diff,
+                                      uint64_t* ov, size_t n, size_t ld, uint8_t* err) {
+    return addsub(c, field, true, a, b, diff, ov, n, ld, err);
+}
+extern "C" long p2e_add_many_witness_batch(p2e_ctx* c, int field, const uint64_t* s, int k, uint64_t* sum,
+                                           uint64_t* ov, size_t n, size_t ld, uint8_t* err) {
+    if (bad_common(c, n, ld) || !s || !sum || !ov || !err || (field != 0 && field != 1) || k < 1 || k > 8) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    Staged S(c);
+    s = S.in(s, (size_t)k * 9 * ld * 8);
+    sum = S.out(sum, 9 * ld * 8);
+    ov = S.out(ov, n * 8);
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    if (field == 0)
+        hipLaunchKernelGGL(k_add_many<ModP>, grid1(n), dim3(BS), 0, c->stream, s, k, sum, ov, n, ld, err, c->d_counter);
+    else
+        hipLaunchKernelGGL(k_add_many<ModN>, grid1(n), dim3(BS), 0, c->stream, s, k, sum, ov, n, ld, err, c->d_counter);
+    return S.done(finish_call(c));
+}
+extern "C" long p2e_inv_witness_batch(p2e_ctx* c, int field, const uint64_t* x, uint64_t* inv, uint64_t* div,
+                                      size_t n, size_t ld, uint8_t* err) {
+    if (bad_common(c, n, ld) || !x || !inv || !div || !err || (field != 0 && field != 1)) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    Staged S(c);
+    x = S.in(x, 9 * ld * 8);
+    inv = S.out(inv, 9 * ld * 8);
+    div = S.out(div, 9 * ld * 8);
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    if (field == 0)
+        hipLaunchKernelGGL(k_inv<ModP>, grid1(n), dim3(BS), 0, c->stream, x, inv, div, n, ld, err, c->d_counter);
+    else
+        hipLaunchKernelGGL(k_inv<ModN>, grid1(n), dim3(BS), 0, c->stream, x, inv, div, n, ld, err, c->d_counter);
+    return S.done(finish_call(c));
+}
+extern "C" long p2e_glv_decompose_batch(p2e_ctx* c, const uint64_t* k, uint64_t* k1, uint64_t* k2, uint64_t* n1,
+                                        uint64_t* n2, size_t n, size_t ld, uint8_t* err) {
+    if (bad_common(c, n, ld) || !k || !k1 || !k2 || !n1 || !n2 || !err) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    Staged S(c);
+    k = S.in(k, 9 * ld * 8);
+    k1 = S.out(k1, 5 * ld * 8);
+    k2 = S.out(k2, 5 * ld * 8);
+    n1 = S.out(n1, n * 8);
+    n2 = S.out(n2, n * 8);
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    hipLaunchKernelGGL(k_glv, grid1(n), dim3(BS), 0, c->stream, k, k1, k2, n1, n2, n, ld, err, c->d_counter);
+    return S.done(finish_call(c));
+}
+extern "C" long p2e_limb_split(p2e_ctx* c, const uint8_t* packed, uint64_t* limbs, size_t n, size_t ld) {
+    if (bad_common(c, n, ld) || !packed || !limbs) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    Staged S(c);
+    packed = S.in(packed, n * 32);
+    limbs = S.out(limbs, 9 * ld * 8);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    size_t pairs = (n + 1) / 2;
+    size_t blocks = (pairs + BS - 1) / BS;
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride above 16 workgroups per CU
+    hipLaunchKernelGGL(k_split, dim3((unsigned)blocks), dim3(BS), 0, c->stream, packed, limbs, n, ld);
+    return S.done(finish_call(c));
+}
+extern "C" long p2e_limb_pack(p2e_ctx* c, const uint64_t* limbs, uint8_t* packed, size_t n, size_t ld, uint8_t* err) {
+    if (bad_common(c, n, ld) || !packed || !limbs || !err) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    Staged S(c);
+    limbs = S.in(limbs, 9 * ld * 8);
+    packed = S.out(packed, n * 32);
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    hipLaunchKernelGGL(k_pack, grid1(n), dim3(BS), 0, c->stream, limbs, packed, n, ld, err, c->d_counter);
+    return S.done(finish_call(c));
+}
+
+// ====================================================================================================
+// fused schedules
+// ====================================================================================================
+static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8_t* r, const uint8_t* s,
+                        const uint8_t* pkx, const uint8_t* pky, uint64_t* cols, size_t n, size_t ld, uint8_t* err,
+                        uint8_t* valid) {
+    const DeviceProgram& DP = c->progs[program];
+    const Program& G = DP.prog;
+    Staged S(c);
+    msg = S.in(msg, n * 32);
+    r = S.in(r, n * 32);
+    s = S.in(s, n * 32);
+    pkx = S.in(pkx, n * 32);
+    pky = S.in(pky, n * 32);
+    cols = S.out(cols, (size_t)G.num_cols * ld * 8);
+    err = S.out(err, n);
+    valid = S.out(valid, n);
+    if (S.rc) return S.done(S.rc);
+    ScratchLayout L = scratch_layout(G, n);
+    int rc = ensure_scratch(c, L.total);
+    if (rc) return S.done(rc);
+    char* base = (char*)c->scratch;
+    Buffers B{};
+    B.msg = msg;
+    B.r = r;
+    B.s = s;
+    B.pkx = pkx;
+    B.pky = pky;
+    B.out = cols;
+    B.ld = ld;
+    B.n = n;
+    B.err = (u32*)(base + L.err32);
+    B.valid = (uint8_t*)(base + L.valid8);
+    B.PX = (U256*)(base + L.px);
+    B.PY = (U256*)(base + L.py);
+    B.PZ = (U256*)(base + L.pz);
+    B.PW = (U256*)(base + L.pw);
+    B.PREF = (U256*)(base + L.pref);
+    B.dig4 = (uint8_t*)(base + L.dig4);
+    B.dig2 = (uint8_t*)(base + L.dig2);
+    B.dyn = (uint16_t*)(base + L.dyn);
+    B.cpts = c->d_cpts;
+    B.fbtab = c->d_fbtab;
+    B.ops = DP.d_ops;
+    ZERO_COUNTER(c);
+    unsigned gx = (unsigned)((n + BS - 1) / BS);
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(k_scalar, dim3(gx), dim3(BS), 0, c->stream, G, B);
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    for (int st = 0; st < G.num_stages; st++) {
+        int f = G.stage_first_chain[st], l = G.stage_first_chain[st + 1];
+        hipLaunchKernelGGL(k_chains, dim3(gx, (unsigned)(l - f)), dim3(BS), 0, c->stream, G, B, f);
+    }
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    unsigned chunks = (unsigned)((G.num_ops + BINV_CHUNK - 1) / BINV_CHUNK);
+    hipLaunchKernelGGL(k_batch_inv, dim3(gx, chunks), dim3(BS), 0, c->stream, G, B);
+    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    hipLaunchKernelGGL(k_expand, dim3(gx, (unsigned)G.num_ops), dim3(BS), 0, c->stream, G, B);
+    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+    hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, B.err, B.valid, err, valid, n, c->d_counter);
+    c->have_phases = true;
+    return S.done(finish_call(c));
+}
+
+extern "C" long p2e_ecdsa_verify_witness_batch(p2e_ctx* c, const uint8_t* msg32, const uint8_t* r32,
+                                               const uint8_t* s32, const uint8_t* pkx32, const uint8_t* pky32,
+                                               uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid) {
+    if (bad_common(c, n, ld) || !msg32 || !r32 || !s32 || !pkx32 || !pky32 || !cols || !err) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    return run_program(c, 0, msg32, r32, s32, pkx32, pky32, cols, n, ld, err, valid);
+}
+extern "C" long p2e_glv_mul_witness_batch(p2e_ctx* c, const uint8_t* px32, const uint8_t* py32, const uint8_t* k32,
+                                          uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid) {
+    if (bad_common(c, n, ld) || !px32 || !py32 || !k32 || !cols || !err) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    return run_program(c, 1, k32, k32, k32, px32, py32, cols, n, ld, err, valid);
+}
+
+// ====================================================================================================
+// host-only entry points
+// ====================================================================================================
+extern "C" long p2e_schedule_describe(int program, p2e_gen_desc* out, size_t cap) {
+    if (program < 0 || program > 1) return P2E_E_INVALID;
+    const auto& g = host_program(program).gens;
+    for (size_t i = 0; i < g.size() && i < cap && out; i++) {
+        out[i].kind = g[i].kind;
+        out[i].field = g[i].field;
+        out[i].first_col = g[i].col;
+        out[i].num_cols = g[i].ncols;
+        std::memset(out[i].label, 0, sizeof out[i].label);
+        std::strncpy(out[i].label, g[i].label.c_str(), sizeof(out[i].label) - 1);
+    }
+    return (long)g.size();
+}
+extern "C" long p2e_schedule_num_cols(int program) {
+    if (program < 0 || program > 1) return P2E_E_INVALID;
+    return host_program(program).prog.num_cols;
+}
+extern "C" int p2e_synth_signatures(uint64_t seed, size_t first, size_t n, uint8_t* msg32, uint8_t* r32, uint8_t* s32,
+                                    uint8_t* pkx32, uint8_t* pky32) {
+    if (!msg32 || !r32 || !s32 || !pkx32 || !pky32) return P2E_E_INVALID;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (long long i = 0; i < (long long)n; i++) {
+        U256 msg, r, s;
+        Aff pk;
+        host::synth_signature(seed, first + (size_t)i, msg, r, s, pk);
+        std::memcpy(msg32 + 32 * i, msg.w, 32);
+        std::memcpy(r32 + 32 * i, r.w, 32);
+        std::memcpy(s32 + 32 * i, s.w, 32);
+        std::memcpy(pkx32 + 32 * i, pk.x.w, 32);
+        std::memcpy(pky32 + 32 * i, pk.y.w, 32);
+    }
+    return 0;
+}

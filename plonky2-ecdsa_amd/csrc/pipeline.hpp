@@ -1,0 +1,383 @@
+// Per-lane bodies of the batch witness pipeline for verify_secp256k1_message_circuit and glv_mul
+// (reference gadgets/ecdsa.rs:30-53, gadgets/glv.rs:87-104, gadgets/curve_msm.rs:21-79,
+// gadgets/curve_fixed_base.rs:18-66, gadgets/curve.rs:123-243).
+//
+// The reference's schedule is a fixed list of "curve ops" (curve_add / curve_double /
+// curve_conditional_add), built once on the host by schedule.hpp into an OpDesc table.  The pipeline
+// runs four phases over a batch, every lane = one signature (64 consecutive signatures per wave):
+//   S  scalar      s^-1, u1, u2, curve_assert_valid, GLV decomposition, window digits        (1 thread/sig)
+//   A  chains      every intermediate point in Jacobian form, no inversions (ec.hpp)          (1 thread/sig/chain)
+//   B  batch-inv   Montgomery batch inversion of all Z -> affine points + every v^-1          (1 thread/sig/chunk)
+//   C  expand      the 231/282/251 witness columns of every curve op, fully parallel          (1 thread/sig/op)
+// Phase C writes 98% of the output bytes and is the HBM-bound kernel the roofline is quoted on.
+#pragma once
+#include "ec.hpp"
+#include "wit.hpp"
+
+namespace p2e {
+
+// ---- schedule description shared by host and device ---------------------------------------------------
+enum OpKind : uint8_t { OP_ADD = 0, OP_DBL = 1, OP_CADD = 2 };
+enum RefKind : uint32_t { R_SLOT = 0, R_CONST = 1, R_DYN = 2, R_FBTAB = 3, R_MSMTAB = 4 };
+enum OpFlags : uint8_t { F_Z1ONE = 1, F_Z2ONE = 2, F_CHECK_R = 4 };
+P2E_HD constexpr u32 make_ref(u32 kind, u32 id) { return (kind << 24) | id; }
+P2E_HD constexpr u32 ref_kind(u32 r) { return r >> 24; }
+P2E_HD constexpr u32 ref_id(u32 r) { return r & 0xFFFFFFu; }
+constexpr uint16_t DYN_CONST_BIT = 0x8000;
+
+struct OpDesc {
+    uint8_t kind;       // OpKind
+    uint8_t flags;      // OpFlags
+    uint16_t cadd_idx;  // for OP_CADD: row of the dyn[] array that receives the selected source
+    u32 ref1, ref2;     // operands
+    u32 col;            // first output column
+};
+constexpr int CONST_RANDO = 0, CONST_NEG_RANDO = 1, CONST_NEG_RANDO_146 = 2, NUM_CONST_PTS = 3;
+constexpr int FB_WINDOWS = 66, MSM_DIGITS = 73;
+constexpr int COLS_ADD = 231, COLS_DBL = 282, COLS_CADD = 251;
+
+// column anchors of the non-curve-op part of the schedule (filled by the host walk)
+struct ScalarCols {
+    int32_t assert_valid;  // 224 columns, -1 if absent (glv_mul-only program)
+    int32_t inv_s;         // 18
+    int32_t u1, u2;        // 51 each
+    int32_t glv;           // 12 + 20 + 20 + 51 + 10 = 113
+    int32_t beta_x;        // 51
+    int32_t neg_p, neg_sp; // 20 each
+};
+
+struct Program {
+    int32_t num_ops;        // curve ops
+    int32_t num_slots;      // num_ops + 2 (p_neg, sp_neg)
+    int32_t slot_p, slot_sp;
+    int32_t num_cadd;
+    int32_t full_verify;    // 1: verify circuit, 0: glv_mul only
+    int32_t num_cols;
+    ScalarCols sc;
+    u32 msm_tab[16];        // refs of precomputation[0..15]
+    // phase A stages: chains of consecutive op ranges
+    int32_t num_stages;
+    int32_t stage_first_chain[4];
+    int32_t num_chains;
+    int32_t chain_begin[4], chain_end[4];
+};
+
+struct Buffers {
+    // inputs, packed 32-byte little-endian, element i at +32*i
+    const uint8_t *msg, *r, *s, *pkx, *pky;  // glv_mul-only: pkx, pky, and k in `msg`
+    u64* out;
+    size_t ld, n;
+    u32* err;        // per-element error bits (never null; OR-ed atomically by phases B and C)
+    uint8_t* valid;  // per-element "all connect constraints hold" (never null)
+    // scratch, [slot][n]
+    U256 *PX, *PY, *PZ, *PW, *PREF;
+    uint8_t* dig4;   // [66][n]
+    uint8_t* dig2;   // [73][n]   4*m_d + n_d
+    uint16_t* dyn;   // [num_cadd][n]
+    // constants
+    const Aff* cpts;   // [NUM_CONST_PTS]
+    const Aff* fbtab;  // [66][16]
+    const OpDesc* ops;
+};
+
+P2E_HD void err_or(u32* p, u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(p, v);
+#else
+    *p |= v;
+#endif
+}
+P2E_HD U256 load_packed(const uint8_t* base, size_t i) {
+    const u32* p = reinterpret_cast<const u32*>(base + 32 * i);
+    U256 r;
+    P2E_UNROLL
+    for (int k = 0; k < 8; k++) r.w[k] = p[k];
+    return r;
+}
+P2E_HD U256 u256_from_words(const u32* w) {
+    U256 r;
+    P2E_UNROLL
+    for (int k = 0; k < 8; k++) r.w[k] = w[k];
+    return r;
+}
+// digit t (width WB) of a value = bits [WB*t, WB*t+WB): identical to the reference's per-limb LE bit
+// split + regroup (gadgets/split_nonnative.rs:25-72) because limbs are 29 contiguous bits each
+template <int WB>
+P2E_HD u32 digit_of(const U256& v, int t) {
+    int bit = WB * t;
+    if (bit >= 256) return 0;
+    return (v.w[bit >> 5] >> (bit & 31)) & ((1u << WB) - 1);  // WB divides 32: never straddles
+}
+
+P2E_HD Emit emit_at(const Buffers& B, size_t i, u32 col) {
+    Emit e;
+    e.p = B.out + (size_t)col * B.ld + i;
+    e.ld = B.ld;
+    return e;
+}
+
+// ---- phase S --------------------------------------------------------------------------------------------
+P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
+    uint8_t err = 0;
+    bool ok = true;
+    U256 px = load_packed(B.pkx, i), py = load_packed(B.pky, i);
+    U256 k;  // scalar multiplying pk
+    if (G.full_verify) {
+        U256 msg = load_packed(B.msg, i), r = load_packed(B.r, i), s = load_packed(B.s, i);
+        {  // curve_assert_valid gadgets/curve.rs:123-135
+            Emit e = emit_at(B, i, (u32)G.sc.assert_valid);
+            U256 y2 = wit_mul<ModP>(e, py, py, err);
+            U256 x2 = wit_mul<ModP>(e, px, px, err);
+            U256 x3 = wit_mul<ModP>(e, x2, px, err);
+            U256 ax = wit_mul<ModP>(e, u256_zero(), px, err);
+            U256 axb = wit_add<ModP>(e, ax, u256_small(7));
+            U256 rhs = wit_add<ModP>(e, x3, axb);
+            ok = ok && u256_eq(y2, rhs);
+        }
+        Emit e = emit_at(B, i, (u32)G.sc.inv_s);
+        U256 c = wit_inv<ModN>(e, s, err);        // gadgets/ecdsa.rs:40
+        U256 u1 = wit_mul<ModN>(e, msg, c, err);  // :41
+        k = wit_mul<ModN>(e, r, c, err);          // :42
+        for (int w = 0; w < FB_WINDOWS; w++) B.dig4[(size_t)w * B.n + i] = (uint8_t)digit_of<4>(u1, w);
+    } else {
+        k = load_packed(B.msg, i);
+    }
+    // decompose_secp256k1_scalar gadgets/glv.rs:53-85
+    GlvOut g = glv_decompose(k);
+    {
+        Emit e = emit_at(B, i, (u32)G.sc.glv);
+        u32 l[NL];
+        split29(g.k1, l);
+        emit_limbs(e, l, 5);
+        if (l[5] | l[6] | l[7] | l[8]) err |= ERR_LIMB_RANGE;
+        split29(g.k2, l);
+        emit_limbs(e, l, 5);
+        if (l[5] | l[6] | l[7] | l[8]) err |= ERR_LIMB_RANGE;
+        e.put(g.n1);
+        e.put(g.n2);
+        U256 k1r = wit_cond_neg<ModN>(e, g.k1, g.n1);
+        U256 k2r = wit_cond_neg<ModN>(e, g.k2, g.n2);
+        U256 S;
+        {
+            const u64 sv[4] = {16069571880186789234ull, 1310022930574435960ull, 11900229862571533402ull,
+                               6008836872998760672ull};
+            P2E_UNROLL
+            for (int q = 0; q < 4; q++) {
+                S.w[2 * q] = (u32)sv[q];
+                S.w[2 * q + 1] = (u32)(sv[q] >> 32);
+            }
+        }
+        U256 sb = wit_mul<ModN>(e, S, k2r, err);
+        sb = wit_add<ModN>(e, sb, k1r);
+        // connect_nonnative(should_be_k, k): limb-wise equality with the (raw) k target
+        ok = ok && u256_eq(sb, k);
+    }
+    for (int d = 0; d < MSM_DIGITS; d++)
+        B.dig2[(size_t)d * B.n + i] = (uint8_t)(4 * digit_of<2>(g.k2, d) + digit_of<2>(g.k1, d));
+    // glv_mul gadgets/glv.rs:87-104
+    U256 beta;
+    {
+        const u64 bv[4] = {13923278643952681454ull, 11308619431505398165ull, 7954561588662645993ull,
+                           8856726876819556112ull};
+        P2E_UNROLL
+        for (int q = 0; q < 4; q++) {
+            beta.w[2 * q] = (u32)bv[q];
+            beta.w[2 * q + 1] = (u32)(bv[q] >> 32);
+        }
+    }
+    Emit e1 = emit_at(B, i, (u32)G.sc.beta_x);
+    U256 bx = wit_mul<ModP>(e1, beta, px, err);
+    Emit e2 = emit_at(B, i, (u32)G.sc.neg_p);
+    U256 y1 = wit_cond_neg<ModP>(e2, py, g.n1);
+    Emit e3 = emit_at(B, i, (u32)G.sc.neg_sp);
+    U256 y2 = wit_cond_neg<ModP>(e3, py, g.n2);
+    size_t sp = (size_t)G.slot_p * B.n + i, ssp = (size_t)G.slot_sp * B.n + i;
+    B.PX[sp] = fe_canon<ModP>(px);  // only ever consumed through canonicalising generators
+    B.PY[sp] = y1;
+    B.PX[ssp] = bx;
+    B.PY[ssp] = y2;
+    B.err[i] = err;
+    B.valid[i] = ok ? 1 : 0;
+}
+
+// ---- operand resolution -----------------------------------------------------------------------------------
+// static part of a reference -> per-lane 16-bit source id (slot, or constant | DYN_CONST_BIT)
+P2E_HD uint16_t resolve_src(const Program& G, const Buffers& B, size_t i, u32 ref) {
+    u32 k = ref_kind(ref), id = ref_id(ref);
+    if (k == R_SLOT) return (uint16_t)id;
+    if (k == R_CONST) return (uint16_t)(id | DYN_CONST_BIT);
+    if (k == R_DYN) return B.dyn[(size_t)id * B.n + i];
+    if (k == R_MSMTAB) {
+        u32 t = G.msm_tab[B.dig2[(size_t)id * B.n + i]];
+        return ref_kind(t) == R_CONST ? (uint16_t)(ref_id(t) | DYN_CONST_BIT) : (uint16_t)ref_id(t);
+    }
+    return 0;  // R_FBTAB never goes through here
+}
+P2E_HD Aff load_aff_src(const Buffers& B, size_t i, uint16_t src) {
+    Aff a;
+    if (src & DYN_CONST_BIT) {
+        a = B.cpts[src & 0x7FFF];
+    } else {
+        a.x = B.PX[(size_t)src * B.n + i];
+        a.y = B.PY[(size_t)src * B.n + i];
+    }
+    return a;
+}
+P2E_HD Jac load_jac_src(const Buffers& B, size_t i, uint16_t src, bool z_one) {
+    Jac j;
+    if (src & DYN_CONST_BIT) {
+        Aff a = B.cpts[src & 0x7FFF];
+        j.X = a.x;
+        j.Y = a.y;
+        j.Z = u256_small(1);
+    } else {
+        size_t o = (size_t)src * B.n + i;
+        j.X = B.PX[o];
+        j.Y = B.PY[o];
+        j.Z = z_one ? u256_small(1) : B.PZ[o];
+    }
+    return j;
+}
+P2E_HD Aff load_fbtab(const Buffers& B, size_t i, u32 window, u32& digit) {
+    digit = B.dig4[(size_t)window * B.n + i];
+    return B.fbtab[window * 16 + digit];
+}
+
+// ---- phase A: one op of a chain in Jacobian coordinates -----------------------------------------------
+P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t) {
+    const OpDesc op = B.ops[t];
+    size_t o = (size_t)t * B.n + i;
+    JacW res;
+    uint16_t src1 = resolve_src(G, B, i, op.ref1);
+    Jac p1 = load_jac_src(B, i, src1, (op.flags & F_Z1ONE) != 0);
+    if (op.kind == OP_DBL) {
+        res = jac_dbl(p1);
+    } else {
+        Jac p2;
+        u32 digit = 1;
+        if (ref_kind(op.ref2) == R_FBTAB) {
+            Aff a = load_fbtab(B, i, ref_id(op.ref2), digit);
+            p2 = jac_from_aff(a);
+        } else {
+            if (ref_kind(op.ref2) == R_MSMTAB) digit = B.dig2[(size_t)ref_id(op.ref2) * B.n + i];
+            uint16_t src2 = resolve_src(G, B, i, op.ref2);
+            p2 = load_jac_src(B, i, src2, (op.flags & F_Z2ONE) != 0);
+        }
+        // the Z-one specialisations only skip multiplications by one: pick by the host-known flags
+        if ((op.flags & F_Z1ONE) && (op.flags & F_Z2ONE))
+            res = jac_add<true, true>(p1, p2);
+        else if (op.flags & F_Z2ONE)
+            res = jac_add<false, true>(p1, p2);
+        else if (op.flags & F_Z1ONE)
+            res = jac_add<true, false>(p1, p2);
+        else
+            res = jac_add<false, false>(p1, p2);
+        if (op.kind == OP_CADD) B.dyn[(size_t)op.cadd_idx * B.n + i] = digit != 0 ? (uint16_t)t : src1;
+    }
+    B.PX[o] = res.p.X;
+    B.PY[o] = res.p.Y;
+    B.PZ[o] = res.p.Z;
+    B.PW[o] = res.W;
+}
+P2E_HD void body_chain(const Program& G, const Buffers& B, size_t i, int chain) {
+    for (int t = G.chain_begin[chain]; t < G.chain_end[chain]; t++) body_chain_op(G, B, i, t);
+}
+
+// ---- phase B: Montgomery batch inversion of Z over ops [t0, t1) of one signature ------------------------
+P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0, int t1) {
+    (void)G;
+    uint8_t err = 0;
+    U256 acc = u256_small(1);
+    for (int t = t0; t < t1; t++) {
+        size_t o = (size_t)t * B.n + i;
+        U256 z = B.PZ[o];
+        if (u256_is_zero(z)) {  // reference: inverse() of zero panics (gadgets/nonnative.rs:863)
+            err |= ERR_INVERSE_OF_ZERO;
+            z = u256_small(1);
+            B.PZ[o] = z;
+        }
+        B.PREF[o] = acc;
+        acc = fp_mul(acc, z);
+    }
+    U256 inv = fe_inv_p(acc);
+    for (int t = t1 - 1; t >= t0; t--) {
+        size_t o = (size_t)t * B.n + i;
+        U256 z = B.PZ[o];
+        U256 zi = fp_mul(inv, B.PREF[o]);
+        inv = fp_mul(inv, z);
+        U256 zi2 = fp_sqr(zi);
+        U256 zi3 = fp_mul(zi2, zi);
+        B.PX[o] = fp_mul(B.PX[o], zi2);
+        B.PY[o] = fp_mul(B.PY[o], zi3);
+        B.PW[o] = fp_mul(B.PW[o], zi);  // v^-1 of op t
+    }
+    if (err) err_or(&B.err[i], err);
+}
+
+// ---- phase C: witness columns of one curve op ---------------------------------------------------------------
+// gadgets/curve.rs:202-223
+template <class E>
+P2E_HD Aff wit_curve_add(E& e, const Aff& p1, const Aff& p2, const U256& vinv, uint8_t& err) {
+    U256 u = wit_sub<ModP>(e, p2.y, p1.y);
+    U256 v = wit_sub<ModP>(e, p2.x, p1.x);
+    wit_inv_given<ModP>(e, v, vinv, err);
+    U256 s = wit_mul<ModP>(e, u, vinv, err);
+    U256 s2 = wit_mul<ModP>(e, s, s, err);
+    U256 xs = wit_add<ModP>(e, p2.x, p1.x);
+    Aff r;
+    r.x = wit_sub<ModP>(e, s2, xs);
+    U256 xd = wit_sub<ModP>(e, p1.x, r.x);
+    U256 pr = wit_mul<ModP>(e, s, xd, err);
+    r.y = wit_sub<ModP>(e, pr, p1.y);
+    return r;
+}
+// gadgets/curve.rs:160-185
+template <class E>
+P2E_HD Aff wit_curve_double(E& e, const Aff& p, const U256& vinv, uint8_t& err) {
+    U256 dy = wit_add<ModP>(e, p.y, p.y);
+    wit_inv_given<ModP>(e, dy, vinv, err);
+    U256 xx = wit_mul<ModP>(e, p.x, p.x, err);
+    U256 summ[4] = {xx, xx, xx, u256_zero()};
+    U256 t = wit_add_many<ModP, 4>(e, summ);
+    U256 l = wit_mul<ModP>(e, t, vinv, err);
+    U256 l2 = wit_mul<ModP>(e, l, l, err);
+    U256 xd2 = wit_add<ModP>(e, p.x, p.x);
+    Aff r;
+    r.x = wit_sub<ModP>(e, l2, xd2);
+    U256 xdf = wit_sub<ModP>(e, p.x, r.x);
+    U256 lx = wit_mul<ModP>(e, l, xdf, err);
+    r.y = wit_sub<ModP>(e, lx, p.y);
+    return r;
+}
+P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t) {
+    const OpDesc op = B.ops[t];
+    uint8_t err = 0;
+    Emit e = emit_at(B, i, op.col);
+    U256 vinv = B.PW[(size_t)t * B.n + i];
+    Aff p1 = load_aff_src(B, i, resolve_src(G, B, i, op.ref1));
+    if (op.kind == OP_DBL) {
+        (void)wit_curve_double(e, p1, vinv, err);
+    } else {
+        Aff p2;
+        u32 digit = 1;
+        if (ref_kind(op.ref2) == R_FBTAB) {
+            p2 = load_fbtab(B, i, ref_id(op.ref2), digit);
+        } else {
+            if (ref_kind(op.ref2) == R_MSMTAB) digit = B.dig2[(size_t)ref_id(op.ref2) * B.n + i];
+            p2 = load_aff_src(B, i, resolve_src(G, B, i, op.ref2));
+        }
+        Aff s = wit_curve_add(e, p1, p2, vinv, err);
+        if (op.kind == OP_CADD) {  // gadgets/curve.rs:225-243: sum always computed (Q7), then selected
+            bool b = digit != 0;
+            (void)wit_add<ModP>(e, b ? s.x : u256_zero(), b ? u256_zero() : p1.x);
+            (void)wit_add<ModP>(e, b ? s.y : u256_zero(), b ? u256_zero() : p1.y);
+        }
+        if (op.flags & F_CHECK_R) {  // gadgets/ecdsa.rs:48-52 connect_nonnative(r, point.x)
+            U256 r = load_packed(B.r, i);
+            if (!u256_eq(s.x, r)) B.valid[i] = 0;
+        }
+    }
+    if (err) err_or(&B.err[i], err);
+}
+
+}  // namespace p2e

@@ -1,0 +1,300 @@
+// Witness values of the plonky2-ecdsa non-native generators, one signature (one lane) at a time.
+// Each wit_* function computes exactly what the corresponding reference run_once body would
+// set_target, and emits the values in generator-registration order through an Emit cursor that walks
+// the Goldilocks column matrix  out[col * ld + sig]  (column-major over the batch: a wavefront's 64
+// lanes are 64 consecutive signatures, so every emit is one coalesced 512-byte store).
+//
+// Reference (paths relative to /root/reference/src):
+//   wit_add       gadgets/nonnative.rs:626-645   NonNativeAdditionGenerator::run_once
+//   wit_sub       gadgets/nonnative.rs:792-810   NonNativeSubtractionGenerator::run_once
+//   wit_add_many  gadgets/nonnative.rs:696-728   NonNativeMultipleAddsGenerator::run_once
+//   wit_inv       gadgets/nonnative.rs:857-872   NonNativeInverseGenerator::run_once
+//   wit_mul       gates/mul_nonnative.rs:249-324 MulNonnativeGenerator::run_once
+//                 gates/mul_nonnative.rs:513-531 CheckSumGenerator::run_once
+//   glv_decompose curve/glv.rs:39-77 + gadgets/glv.rs:128-142
+#pragma once
+#include "fe.hpp"
+
+namespace p2e {
+
+// cursor over one signature's column of the output matrix
+struct Emit {
+    u64* p;      // &out[col * ld + sig]
+    size_t ld;   // column stride in elements
+    P2E_HD void put(u64 v) {
+        *p = v;
+        p += ld;
+    }
+};
+// null sink with the same interface (used where only the value is wanted)
+struct NoEmit {
+    P2E_HD void put(u64) {}
+};
+
+template <class E>
+P2E_HD void emit_limbs(E& e, const u32* l, int n) {
+    P2E_UNROLL
+    for (int i = 0; i < NL; i++)
+        if (i < n) e.put((u64)l[i]);
+}
+template <class E>
+P2E_HD void emit_u256(E& e, const U256& v) {
+    u32 l[NL];
+    split29(v, l);
+    emit_limbs(e, l, NL);
+}
+
+// ---- add: returns the sum target value (== m possible, reference quirk Q1: strict '>') ----------
+template <class MOD, class E>
+P2E_HD U256 wit_add(E& e, const U256& a_raw, const U256& b_raw) {
+    U256 a = fe_canon<MOD>(a_raw), b = fe_canon<MOD>(b_raw);
+    U256 s;
+    u32 c = add_n<8>(s.w, a.w, b.w);
+    // s_total = c*2^256 + s ; overflow iff s_total > m  (strictly)
+    bool gt = c != 0;
+    if (!gt) {
+        bool ge = geq_mod<MOD>(s.w);
+        bool eq = true;
+        P2E_UNROLL
+        for (int i = 0; i < 8; i++) eq = eq && (s.w[i] == MOD::m(i));
+        gt = ge && !eq;
+    }
+    if (gt) sub_mod_raw<MOD>(s.w);
+    emit_u256(e, s);
+    e.put(gt ? 1u : 0u);
+    return s;
+}
+
+// ---- sub ------------------------------------------------------------------------------------------
+template <class MOD, class E>
+P2E_HD U256 wit_sub(E& e, const U256& a_raw, const U256& b_raw) {
+    U256 a = fe_canon<MOD>(a_raw), b = fe_canon<MOD>(b_raw);
+    U256 d;
+    u32 br = sub_n<8>(d.w, a.w, b.w);
+    if (br) add_mod_raw<MOD>(d.w);
+    emit_u256(e, d);
+    e.put(br ? 1u : 0u);
+    return d;
+}
+
+// ---- add_many: sum of k canonicalised summands, true div_rem by m -----------------------------------
+template <class MOD, int K, class E>
+P2E_HD U256 wit_add_many(E& e, const U256* xs) {
+    u32 acc[9];
+    P2E_UNROLL
+    for (int i = 0; i < 9; i++) acc[i] = 0;
+    P2E_UNROLL
+    for (int k = 0; k < K; k++) {
+        U256 v = fe_canon<MOD>(xs[k]);
+        u64 c = 0;
+        P2E_UNROLL
+        for (int i = 0; i < 9; i++) {
+            c += (u64)acc[i] + (i < 8 ? v.w[i] : 0u);
+            acc[i] = (u32)c;
+            c >>= 32;
+        }
+    }
+    u32 ov = 0;
+    P2E_UNROLL
+    for (int k = 0; k < K; k++) {  // quotient < K
+        bool ge = acc[8] != 0 || geq_mod<MOD>(acc);
+        if (ge) {
+            u32 br = 0;
+            P2E_UNROLL
+            for (int i = 0; i < 9; i++) {
+                u64 d = (u64)acc[i] - (i < 8 ? MOD::m(i) : 0u) - br;
+                acc[i] = (u32)d;
+                br = (u32)(d >> 63);
+            }
+            ov++;
+        }
+    }
+    U256 s;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) s.w[i] = acc[i];
+    emit_u256(e, s);
+    e.put(ov);
+    return s;
+}
+
+// ---- inv: emits inv[9], div[9] where x*inv = div*m + 1.  `inv` is supplied by the caller (batched
+// inversion) and must be the canonical inverse of canon(x_raw). ------------------------------------
+template <class MOD, class E>
+P2E_HD void wit_inv_given(E& e, const U256& x_raw, const U256& inv, uint8_t& err) {
+    U256 x = fe_canon<MOD>(x_raw);
+    if (u256_is_zero(x)) err |= ERR_INVERSE_OF_ZERO;
+    u32 prod[16], q[9], r[8];
+    mul_wide<8, 8>(x.w, inv.w, prod);
+    reduce_wide<MOD, 8, true>(prod, r, q);
+    emit_u256(e, inv);
+    u32 ql[NL];
+    P2E_UNROLL
+    for (int k = 0; k < NL; k++) ql[k] = limb29<9>(q, k);
+    emit_limbs(e, ql, NL);
+}
+// stand-alone form: one Fermat ladder per call
+template <class MOD, class E>
+P2E_HD U256 wit_inv(E& e, const U256& x_raw, uint8_t& err) {
+    U256 x = fe_canon<MOD>(x_raw);
+    U256 inv = fe_inv<MOD>(x);
+    wit_inv_given<MOD>(e, x, inv, err);
+    return inv;
+}
+
+// ---- mul + checksum ---------------------------------------------------------------------------------
+// un-carried q*m convolution column i, exploiting m29[j] = (2^29-1) - d[j] for p
+template <class MOD>
+P2E_HD u64 qm_column(const u32* q29, int i);
+template <>
+P2E_HD u64 qm_column<ModN>(const u32* q29, int i) {
+    u64 acc = 0;
+    P2E_UNROLL
+    for (int j = 0; j < NL; j++) {
+        int k = i - j;
+        if (k >= 0 && k < NL) acc += (u64)q29[k] * ModN::m29(j);
+    }
+    return acc;
+}
+template <>
+P2E_HD u64 qm_column<ModP>(const u32* q29, int i) {
+    // sum_j q[i-j]*(M - d[j]) with M = 2^29-1, d = {976, 8, 0,0,0,0,0,0, 0x1F000000}
+    u64 w = 0;
+    P2E_UNROLL
+    for (int j = 0; j < NL; j++) {
+        int k = i - j;
+        if (k >= 0 && k < NL) w += q29[k];
+    }
+    u64 acc = (w << BITS) - w;
+    if (i < NL) acc -= (u64)q29[i] * 976u;
+    if (i - 1 >= 0 && i - 1 < NL) acc -= (u64)q29[i - 1] * 8u;
+    if (i - 8 >= 0 && i - 8 < NL) acc -= (u64)q29[i - 8] * 0x1F000000u;
+    return acc;
+}
+
+// core: given 29-bit limbs of x, y (gate wires) and the quotient/remainder, emit r, q, cs, b
+template <class MOD, class E>
+P2E_HD void emit_mul_rows(E& e, const u32* x29, const u32* y29, const u32* q29, const u32* r29, uint8_t& err) {
+    emit_limbs(e, r29, NL);
+    emit_limbs(e, q29, NL);
+    i64 last = 0;
+    u64 bvals[2 * NL - 2];
+    P2E_UNROLL
+    for (int i = 0; i < 2 * NL - 1; i++) {
+        u64 xy = 0;
+        P2E_UNROLL
+        for (int j = 0; j < NL; j++) {
+            int k = i - j;
+            if (k >= 0 && k < NL) xy += (u64)x29[j] * y29[k];
+        }
+        i64 cs = (i64)(qm_column<MOD>(q29, i) - xy) + (i < NL ? (i64)r29[i] : 0);
+        e.put(gl_from_i64(cs));
+        if (i < 2 * NL - 2) {
+            i64 t = cs + last;
+            i64 bi = t >> BITS;  // exact: the integer is a multiple of 2^29 whenever q, r are right
+            u64 bo = (u64)(bi + ((i64)1 << 33));
+            if (bo >> 34) err |= ERR_CARRY_RANGE;
+            bvals[i] = bo;
+            last = bi;
+        }
+    }
+    P2E_UNROLL
+    for (int i = 0; i < 2 * NL - 2; i++) e.put(bvals[i]);
+}
+
+// x, y: the values carried by the two operands' limbs (used RAW: reference quirk Q3), < 2^256
+template <class MOD, class E>
+P2E_HD U256 wit_mul(E& e, const U256& x, const U256& y, uint8_t& err) {
+    u32 prod[16], q[9];
+    U256 r;
+    mul_wide<8, 8>(x.w, y.w, prod);
+    reduce_wide<MOD, 8, true>(prod, r.w, q);
+    u32 x29[NL], y29[NL], q29[NL], r29[NL];
+    split29(x, x29);
+    split29(y, y29);
+    split29(r, r29);
+    P2E_UNROLL
+    for (int k = 0; k < NL; k++) q29[k] = limb29<9>(q, k);
+    emit_mul_rows<MOD>(e, x29, y29, q29, r29, err);
+    return r;
+}
+
+// ---- nonnative_conditional_neg (gadgets/nonnative.rs:584-596): sub(0, x) then add(neg*b, x*!b) ----
+template <class MOD, class E>
+P2E_HD U256 wit_cond_neg(E& e, const U256& x, u32 b) {
+    U256 neg = wit_sub<MOD>(e, u256_zero(), x);
+    U256 t = b ? neg : u256_zero();
+    U256 f = b ? u256_zero() : x;
+    return wit_add<MOD>(e, t, f);
+}
+
+// ---- GLV decomposition --------------------------------------------------------------------------------
+struct GlvOut {
+    U256 k1, k2;   // |k1|, |k2|
+    u32 n1, n2;    // signs
+};
+P2E_HD U256 glv_round_div(const U256& k, const u32* c4 /*4 words*/) {
+    // round(c*k / n) with num Ratio::round semantics for odd n: +1 iff 2*rem > n
+    u32 prod[12], q[9], r[8];
+    mul_wide<8, 4>(k.w, c4, prod);
+    reduce_wide<ModN, 4, true>(prod, r, q);
+    // 2*rem > n  <=>  rem > (n-1)/2  <=>  rem >= (n+1)/2
+    u32 r2[9];
+    u32 cw = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) {
+        r2[i] = (r[i] << 1) | cw;
+        cw = r[i] >> 31;
+    }
+    r2[8] = cw;
+    bool gt = r2[8] != 0;
+    if (!gt) {
+        bool ge = geq_mod<ModN>(r2);
+        bool eq = true;
+        P2E_UNROLL
+        for (int i = 0; i < 8; i++) eq = eq && (r2[i] == ModN::m(i));
+        gt = ge && !eq;
+    }
+    U256 out;
+    u64 c = gt ? 1 : 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) {
+        c += q[i];
+        out.w[i] = (u32)c;
+        c >>= 32;
+    }
+    return out;
+}
+P2E_HD GlvOut glv_decompose(const U256& k_raw) {
+    // constants as u64 pairs from curve/glv.rs:25-32
+    const u32 a1[8] = {(u32)16747920425669159701ull, (u32)(16747920425669159701ull >> 32),
+                       (u32)3496713202691238861ull, (u32)(3496713202691238861ull >> 32), 0, 0, 0, 0};
+    const u32 mb1[8] = {(u32)8022177200260244675ull, (u32)(8022177200260244675ull >> 32),
+                        (u32)16448129721693014056ull, (u32)(16448129721693014056ull >> 32), 0, 0, 0, 0};
+    const u32 a2[8] = {(u32)6323353552219852760ull, (u32)(6323353552219852760ull >> 32),
+                       (u32)1498098850674701302ull, (u32)(1498098850674701302ull >> 32), 1, 0, 0, 0};
+    U256 k = fe_canon<ModN>(k_raw);
+    U256 c1 = glv_round_div(k, a1 /* B2 == A1 */);
+    U256 c2 = glv_round_div(k, mb1);
+    U256 A1v, MB1v, A2v;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) {
+        A1v.w[i] = a1[i];
+        MB1v.w[i] = mb1[i];
+        A2v.w[i] = a2[i];
+    }
+    U256 k1 = fe_sub<ModN>(fe_sub<ModN>(k, fe_mul<ModN>(c1, A1v)), fe_mul<ModN>(c2, A2v));
+    U256 k2 = fe_sub<ModN>(fe_mul<ModN>(c1, MB1v), fe_mul<ModN>(c2, A1v));
+    // half = n / 2 (integer division)
+    u32 half[8];
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) half[i] = (ModN::m(i) >> 1) | (i < 7 ? (ModN::m(i + 1) << 31) : 0u);
+    GlvOut o;
+    // k > half  <=>  !(half >= k)
+    o.n1 = geq_n<8>(half, k1.w) ? 0u : 1u;
+    o.n2 = geq_n<8>(half, k2.w) ? 0u : 1u;
+    o.k1 = o.n1 ? fe_sub<ModN>(u256_zero(), k1) : k1;
+    o.k2 = o.n2 ? fe_sub<ModN>(u256_zero(), k2) : k2;
+    return o;
+}
+
+}  // namespace p2e

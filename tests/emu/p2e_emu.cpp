@@ -1,0 +1,104 @@
+// CPU emulation harness -- TEST INFRASTRUCTURE ONLY (never loaded by the product path).
+// Compiles the very same per-lane bodies the HIP kernels run (pipeline.hpp / prims.hpp) with g++ and
+// drives them with plain loops, phase by phase, so kernel logic can be debugged in the GPU-less dev
+// container.  tests/ compare its output with the oracle; the GPU tests then compare the real kernels.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../plonky2-ecdsa_amd/csrc/consts.hpp"
+#include "../../plonky2-ecdsa_amd/csrc/pipeline.hpp"
+#include "../../plonky2-ecdsa_amd/csrc/prims.hpp"
+#include "../../plonky2-ecdsa_amd/csrc/schedule.hpp"
+
+using namespace p2e;
+
+static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx,
+                const uint8_t* pky, uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid, int chunk) {
+    host::ScheduleBuilder sb;
+    if (program == 0)
+        sb.verify_secp256k1_message_circuit();
+    else
+        sb.glv_mul_circuit();
+    const Program& G = sb.prog;
+    const host::Consts& C = host::consts();
+    std::vector<U256> PX((size_t)G.num_slots * n), PY((size_t)G.num_slots * n), PZ((size_t)G.num_ops * n),
+        PW((size_t)G.num_ops * n), PREF((size_t)G.num_ops * n);
+    std::vector<uint8_t> dig4((size_t)FB_WINDOWS * n), dig2((size_t)MSM_DIGITS * n), valid8(n);
+    std::vector<uint16_t> dyn((size_t)G.num_cadd * n);
+    std::vector<u32> err32(n);
+    Buffers B{};
+    B.msg = msg; B.r = r; B.s = s; B.pkx = pkx; B.pky = pky;
+    B.out = cols; B.ld = ld; B.n = n;
+    B.err = err32.data(); B.valid = valid8.data();
+    B.PX = PX.data(); B.PY = PY.data(); B.PZ = PZ.data(); B.PW = PW.data(); B.PREF = PREF.data();
+    B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data();
+    B.cpts = C.cpts; B.fbtab = C.fbtab.data(); B.ops = sb.ops.data();
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)n; i++) body_scalar(G, B, (size_t)i);
+    for (int st = 0; st < G.num_stages; st++) {
+        int f = G.stage_first_chain[st], l = G.stage_first_chain[st + 1];
+#pragma omp parallel for collapse(2)
+        for (int c = f; c < l; c++)
+            for (long long i = 0; i < (long long)n; i++) body_chain(G, B, (size_t)i, c);
+    }
+    int chunks = (G.num_ops + chunk - 1) / chunk;
+    for (int c = 0; c < chunks; c++) {
+        int t0 = c * chunk, t1 = t0 + chunk < G.num_ops ? t0 + chunk : G.num_ops;
+#pragma omp parallel for
+        for (long long i = 0; i < (long long)n; i++) body_batch_inv(G, B, (size_t)i, t0, t1);
+    }
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)n; i++)
+        for (int t = 0; t < G.num_ops; t++) body_expand(G, B, (size_t)i, t);
+    long bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        err[i] = (uint8_t)err32[i];
+        if (valid) valid[i] = err32[i] ? 0 : valid8[i];
+        bad += err32[i] != 0;
+    }
+    return bad;
+}
+
+extern "C" {
+long emu_verify(const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx, const uint8_t* pky,
+                uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid, int chunk) {
+    return run(0, msg, r, s, pkx, pky, cols, n, ld, err, valid, chunk);
+}
+long emu_glv_mul(const uint8_t* px, const uint8_t* py, const uint8_t* k, uint64_t* cols, size_t n, size_t ld,
+                 uint8_t* err, uint8_t* valid, int chunk) {
+    return run(1, k, k, k, px, py, cols, n, ld, err, valid, chunk);
+}
+#define LOOP(expr)                                  \
+    long bad = 0;                                   \
+    for (size_t i = 0; i < n; i++) {                \
+        uint8_t e = (expr);                         \
+        err[i] = e;                                 \
+        bad += e != 0;                              \
+    }                                               \
+    return bad;
+long emu_mul(int field, const u64* x, const u64* y, u64* r, u64* q, u64* cs, u64* b, size_t n, size_t ld, uint8_t* err) {
+    LOOP(field ? prim_mul<ModN>(x, y, r, q, cs, b, ld, i) : prim_mul<ModP>(x, y, r, q, cs, b, ld, i))
+}
+long emu_checksum(const u64* a, u64* b, size_t n, size_t ld, uint8_t* err) { LOOP(prim_checksum(a, b, ld, i)) }
+long emu_add(int field, const u64* a, const u64* b, u64* out, u64* ov, size_t n, size_t ld, uint8_t* err) {
+    LOOP(field ? (prim_addsub<ModN, false>(a, b, out, ov, ld, i)) : (prim_addsub<ModP, false>(a, b, out, ov, ld, i)))
+}
+long emu_sub(int field, const u64* a, const u64* b, u64* out, u64* ov, size_t n, size_t ld, uint8_t* err) {
+    LOOP(field ? (prim_addsub<ModN, true>(a, b, out, ov, ld, i)) : (prim_addsub<ModP, true>(a, b, out, ov, ld, i)))
+}
+long emu_add_many(int field, const u64* s, int k, u64* out, u64* ov, size_t n, size_t ld, uint8_t* err) {
+    LOOP(field ? prim_add_many<ModN>(s, k, out, ov, ld, i) : prim_add_many<ModP>(s, k, out, ov, ld, i))
+}
+long emu_inv(int field, const u64* x, u64* inv, u64* div, size_t n, size_t ld, uint8_t* err) {
+    LOOP(field ? prim_inv<ModN>(x, inv, div, ld, i) : prim_inv<ModP>(x, inv, div, ld, i))
+}
+long emu_glv(const u64* k, u64* k1, u64* k2, u64* n1, u64* n2, size_t n, size_t ld, uint8_t* err) {
+    LOOP(prim_glv(k, k1, k2, n1, n2, ld, i))
+}
+long emu_split(const uint8_t* packed, u64* limbs, size_t n, size_t ld) {
+    for (size_t i = 0; i < n; i++) prim_split(packed, limbs, ld, i);
+    return 0;
+}
+long emu_pack(const u64* limbs, uint8_t* packed, size_t n, size_t ld, uint8_t* err) { LOOP(prim_pack(limbs, packed, ld, i)) }
+}
