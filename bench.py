@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: secp256k1 ECDSA witness fills/sec at batch 2^16 per GPU (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (p2e_ecdsa_verify_witness_batch: all 82 615 hot-path generator
+outputs of verify_secp256k1_message_circuit) over one batch of 2^16 synthetic valid signatures PER GPU,
+inputs already resident in HBM, output columns written to HBM.  One process per GPU; the batch is
+sharded by contiguous signature ranges with no data-path collective ("scaling": "weak": per-GPU work is
+fixed as N grows).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     the dominant kernel (k_expand: writes 82 067 of the 82 615 columns).  achieved =
+               algorithmic bytes per launch / average launch duration, the duration measured live with
+               HIP events on the stream the kernel runs on (p2e_last_phase_ms).  traffic = HBM bytes per
+               launch from the rocprofv3 PMC summary committed under profiles/ (null if absent).
+  cpu_baseline oracle/libp2e_oracle.so (C restatement of the reference's CPU algorithm: affine ops, one
+               Fermat inversion per inverse, OpenMP over signatures) timed on a bounded sample on the
+               host cores of this box.  kind "port": the Rust reference cannot be built offline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_FILL = 661080          # 160 B packed inputs + 82 615 * 8 B outputs
+EXPAND_COLS = 82067              # columns written by k_expand (all curve-op generators)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def usable_cores(omp_max):
+    """Threads this process may really run: affinity mask and cgroup CPU quota, not the host's core count."""
+    n = omp_max
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(p2e, seed):
+    """Bounded-sample timing of the C oracle on the host cores (checker timed as a baseline only)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c
+    cores = usable_cores(oracle_c.max_threads())
+    n = max(64, 100 * cores)                                  # ~25 ms per fill per thread -> 10-20 s
+    sigs = p2e.synth_signatures(seed=seed, n=n)
+    oracle_c.verify_witness(*[a[:cores] for a in sigs], nthreads=cores)   # warm-up (constant tables, threads)
+    t = time.time()
+    cols, err, flags = oracle_c.verify_witness(*sigs, nthreads=cores)
+    dt = time.time() - t
+    assert not err.any() and flags.all()
+    return {"value": round(n / dt, 2), "unit": "fills/s", "cores": cores, "kind": "port",
+            "sample": f"{n} signatures of the same synthetic batch, all {cores} host threads (OpenMP), "
+                      f"{dt:.1f} s; oracle/p2e_oracle.c (schoolbook mul + Knuth D, one Fermat ladder per inverse)"}
+
+
+def pmc_traffic():
+    """HBM bytes per k_expand launch from the committed rocprofv3 PMC summary, if any."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("_pmc_summary.json"):
+                try:
+                    best = json.load(open(os.path.join(pdir, f)))
+                except Exception:
+                    pass
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-log2", type=int, default=16, help="signatures per GPU = 2^k (metric: 16)")
+    ap.add_argument("--allgather-cols", type=int, default=0,
+                    help="N>1 only: after the timed region, all-gather this many columns over RCCL and report GB/s")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import plonky2_ecdsa_amd as p2e
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    n = 1 << args.batch_log2
+    total = n * world
+    from plonky2_ecdsa_amd.dist import shard_bounds
+    start, end = shard_bounds(total, rank, world)
+    sigs = p2e.synth_signatures(seed=4, n=end - start, first=start)       # seed 0x4: SURVEY.md 8(d) cfg-4
+    ctx = p2e.Context(device=local_rank)                                   # runs on torch's current stream
+    inputs = [torch.from_numpy(a).to(dev) for a in sigs]
+    cols = torch.empty((p2e.VERIFY_COLS, n), dtype=torch.int64, device=dev)
+    err = torch.empty(n, dtype=torch.uint8, device=dev)
+    valid = torch.empty(n, dtype=torch.uint8, device=dev)
+
+    def step():
+        return ctx.ecdsa_verify_witness_batch(*inputs, cols=cols, err=err, valid=valid)[3]
+
+    for _ in range(args.warmup):
+        bad = step()
+    torch.cuda.synchronize()
+    if args.warmup:
+        assert bad == 0 and int(valid.sum()) == n, "synthetic signatures must all verify"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    expand_ms = []
+    phase_acc = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        ph = ctx.last_phase_ms()
+        expand_ms.append(ph["expand"])
+        for k, v in ph.items():
+            phase_acc[k] = phase_acc.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    gather = None
+    if world > 1 and args.allgather_cols > 0:
+        from plonky2_ecdsa_amd.dist import all_gather_columns
+        k = min(args.allgather_cols, p2e.VERIFY_COLS)
+        barrier()
+        tg = time.perf_counter()
+        g = all_gather_columns(cols[:k], total)
+        barrier()
+        tg = time.perf_counter() - tg
+        gather = {"cols": k, "bytes_per_rank_out": int(g.numel() * 8), "ms": round(tg * 1e3, 3),
+                  "GBps_per_rank": round(g.numel() * 8 / tg / 1e9, 1)}
+        del g
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total * args.steps / elapsed
+        avg_expand_s = sum(expand_ms) / len(expand_ms) / 1e3
+        alg_bytes = EXPAND_COLS * 8 * n
+        achieved = alg_bytes / avg_expand_s / 1e9
+        pmc = pmc_traffic()
+        line = {
+            "metric": "secp256k1 ECDSA witness fills/sec at batch=2^16, 1/2/4/8 MI355X; bit-exact",
+            "value": round(value, 1), "unit": "fills/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"batch 2^{args.batch_log2} ECDSA verifies per GPU (BASELINE configs[3] workload on "
+                                   "one GPU; random valid signatures, seed 4), all 82615 hot-path generator columns, "
+                                   "column-major u64 in HBM",
+                       "batch_per_gpu": n, "global_batch": total, "cols_per_fill": p2e.VERIFY_COLS,
+                       "parallelism": f"shard{world}" if world > 1 else "single"},
+            "whole_fill": {"algorithmic_bytes_per_fill": BYTES_PER_FILL,
+                           "GBps_per_gpu": round(value * BYTES_PER_FILL / world / 1e9, 1),
+                           "frac_of_hbm_peak": round(value * BYTES_PER_FILL / world / 1e9 / HBM_PEAK_GBS, 4)},
+            "phase_ms_per_step": {k: round(v / args.steps, 4) for k, v in phase_acc.items()},
+            "roofline": {"kernel": "k_expand", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_expand_s * 1e3, 4),
+                         "traffic": (pmc or {}).get("hbm_bytes_per_launch"),
+                         "traffic_source": (pmc or {}).get("source")},
+        }
+        if gather:
+            line["allgather"] = gather
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(p2e, seed=4)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,7 @@ ERR_LIMB_RANGE = 1        # gates/mul_nonnative.rs:262,271,275-276 ; gadgets/big
 ERR_VALUE_GE_2_256 = 2    # Secp256K1*::from_noncanonical_biguint (template field/p256_base.rs:121-130)
 ERR_INVERSE_OF_ZERO = 4   # gadgets/nonnative.rs:863
 ERR_CARRY_RANGE = 8       # gates/mul_nonnative.rs:527
+ERR_QUOTIENT_RANGE = 16   # q does not fit the gate's nine q wires (documented deviation: flagged, not emitted)
 
 
 class RefPanic(Exception):
@@ -296,6 +297,10 @@ def gen_mul(x_limbs, y_limbs, m):
     q, r = divmod(x * y, m)
     q29 = convert_base(to_u32_digits(q), 32, BITS)
     r29 = convert_base(to_u32_digits(r), 32, BITS)
+    if len(q29) > NL:
+        # The reference would set only q[0..9] and produce an unsatisfiable witness (CheckSumGenerator
+        # then usually panics at :527).  Outside the gate's domain; we flag it instead.
+        raise RefPanic(ERR_QUOTIENT_RANGE, "quotient does not fit 9 limbs")
     q29 += [0] * max(0, NL - len(q29))
     r29 += [0] * max(0, NL - len(r29))
     m29 += [0] * max(0, NL - len(m29))

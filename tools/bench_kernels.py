@@ -1,0 +1,56 @@
+"""Stand-alone generator kernels: achieved HBM GB/s (algorithmic bytes / HIP-event time).
+  limb split  104 B/elem (32 in + 72 out)   -- north star: >= 40 % of HBM peak
+  mul witness 552 B/elem (144 in + 408 out) -- BASELINE config 2 shape, swept up in n
+Prints one JSON line per measurement."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import plonky2_ecdsa_amd as p2e
+
+PEAK = 8000.0
+ctx = p2e.Context(device=0)
+reps = int(os.environ.get("REPS", "10"))
+
+
+def timed(fn):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+which = sys.argv[1:] or ["split", "mul", "pack"]
+if "split" in which:
+    for lg in (20, 24, 26):
+        n = 1 << lg
+        packed = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda")
+        limbs = torch.empty((9, n), dtype=torch.int64, device="cuda")
+        ms = timed(lambda: ctx.limb_split(packed, out=limbs))
+        gbs = n * 104 / ms / 1e6
+        print(json.dumps({"kernel": "k_split", "n": n, "ms": round(ms, 4), "alg_bytes": n * 104,
+                          "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK, 4)}), flush=True)
+        del packed, limbs
+if "mul" in which:
+    for lg in (12, 16, 20, 22):
+        n = 1 << lg
+        x = torch.randint(0, 1 << 29, (9, n), dtype=torch.int64, device="cuda")
+        y = torch.randint(0, 1 << 29, (9, n), dtype=torch.int64, device="cuda")
+        x[8] &= (1 << 24) - 1
+        y[8] &= (1 << 24) - 1
+        for field in (0, 1):
+            ms = timed(lambda: ctx.mul_witness_batch(field, x, y))
+            gbs = n * 552 / ms / 1e6
+            print(json.dumps({"kernel": "k_mul", "field": field, "n": n, "ms": round(ms, 4), "alg_bytes": n * 552,
+                              "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK, 4),
+                              "note": "includes output allocation by the python wrapper"}), flush=True)
+        del x, y
