@@ -12,7 +12,8 @@ sharded by contiguous signature ranges with no data-path collective ("scaling": 
 fixed as N grows).  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     the dominant kernel (k_expand: writes 82 067 of the 82 615 columns).  achieved =
+  roofline     the dominant kernel, k_expand (writes 82 067 of the 82 615 columns; launched once per
+               schedule segment, 5 launches per step by default).  achieved =
                algorithmic bytes per launch / average launch duration, the duration measured live with
                HIP events on the stream the kernel runs on (p2e_last_phase_ms).  traffic = HBM bytes per
                launch from the rocprofv3 PMC summary committed under profiles/ (null if absent).
@@ -30,7 +31,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_FILL = 661080          # 160 B packed inputs + 82 615 * 8 B outputs
-EXPAND_COLS = 82067              # columns written by k_expand (all curve-op generators)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=16, help="signatures per GPU = 2^k (metric: 16)")
     ap.add_argument("--allgather-cols", type=int, default=0,
                     help="N>1 only: after the timed region, all-gather this many columns over RCCL and report GB/s")
+    ap.add_argument("--ld-pad", type=int, default=16, help="column stride = batch + this many elements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -115,12 +116,16 @@ def main():
     sigs = p2e.synth_signatures(seed=4, n=end - start, first=start)       # seed 0x4: SURVEY.md 8(d) cfg-4
     ctx = p2e.Context(device=local_rank)                                   # runs on torch's current stream
     inputs = [torch.from_numpy(a).to(dev) for a in sigs]
-    cols = torch.empty((p2e.VERIFY_COLS, n), dtype=torch.int64, device=dev)
+    # column stride: n + 16 elements.  A power-of-two stride (2^16 * 8 B = 512 KiB) makes consecutive columns
+    # camp on the same HBM channels (measured -9 % on k_expand); ld is part of the C ABI (ld >= n).
+    ld = n + args.ld_pad
+    cols_buf = torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device=dev)
+    cols = cols_buf[:, :n]
     err = torch.empty(n, dtype=torch.uint8, device=dev)
     valid = torch.empty(n, dtype=torch.uint8, device=dev)
 
     def step():
-        return ctx.ecdsa_verify_witness_batch(*inputs, cols=cols, err=err, valid=valid)[3]
+        return ctx.ecdsa_verify_witness_batch(*inputs, cols=cols, err=err, valid=valid, ld=ld)[3]
 
     for _ in range(args.warmup):
         bad = step()
@@ -133,7 +138,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    expand_ms = []
+    expand_ms, expand_cols, expand_launches = [], 0.0, 0
     phase_acc = {}
     barrier()
     t0 = time.perf_counter()
@@ -141,8 +146,9 @@ def main():
         step()
         ph = ctx.last_phase_ms()
         expand_ms.append(ph["expand"])
-        for k, v in ph.items():
-            phase_acc[k] = phase_acc.get(k, 0.0) + v
+        expand_cols, expand_launches = ph["expand_cols"], int(ph["expand_launches"])
+        for k in ("scalar", "expand", "total"):
+            phase_acc[k] = phase_acc.get(k, 0.0) + ph[k]
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -166,8 +172,9 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed
-        avg_expand_s = sum(expand_ms) / len(expand_ms) / 1e3
-        alg_bytes = EXPAND_COLS * 8 * n
+        # k_expand runs as `expand_launches` launches per step (one per schedule segment); per launch:
+        avg_expand_s = sum(expand_ms) / len(expand_ms) / 1e3 / expand_launches
+        alg_bytes = int(expand_cols) * 8 * n // expand_launches
         achieved = alg_bytes / avg_expand_s / 1e9
         pmc = pmc_traffic()
         line = {
@@ -178,7 +185,7 @@ def main():
             "config": {"workload": f"batch 2^{args.batch_log2} ECDSA verifies per GPU (BASELINE configs[3] workload on "
                                    "one GPU; random valid signatures, seed 4), all 82615 hot-path generator columns, "
                                    "column-major u64 in HBM",
-                       "batch_per_gpu": n, "global_batch": total, "cols_per_fill": p2e.VERIFY_COLS,
+                       "batch_per_gpu": n, "global_batch": total, "cols_per_fill": p2e.VERIFY_COLS, "ld": ld,
                        "parallelism": f"shard{world}" if world > 1 else "single"},
             "whole_fill": {"algorithmic_bytes_per_fill": BYTES_PER_FILL,
                            "GBps_per_gpu": round(value * BYTES_PER_FILL / world / 1e9, 1),
@@ -187,7 +194,8 @@ def main():
             "roofline": {"kernel": "k_expand", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_expand_s * 1e3, 4),
-                         "traffic": (pmc or {}).get("hbm_bytes_per_launch"),
+                         "launches_per_step": expand_launches, "cols_per_fill_all_launches": int(expand_cols),
+                         "traffic": (pmc or {}).get("hbm_bytes_per_launch_avg"),
                          "traffic_source": (pmc or {}).get("source")},
         }
         if gather:

@@ -71,8 +71,11 @@ int p2e_sync(p2e_ctx *ctx);
 const char *p2e_last_error(void);
 /* bytes of device scratch the fused entry points need for a batch of n (allocated lazily, kept) */
 size_t p2e_scratch_bytes(int program /*0 verify, 1 glv_mul*/, size_t n);
-/* milliseconds of the last call per pipeline phase, measured with hipEvents on the context's stream:
- * out[0..4] = scalar, chains, batch-inverse, expand, total.  Returns the number written. */
+/* Timing of the last fused call, measured with hipEvents on the context's stream:
+ * out[0] = ms of the scalar kernel, out[1] = number of k_expand launches (the schedule is cut into
+ * segments whose Jacobian chains run on internal streams underneath), out[2] = witness columns per
+ * signature those launches wrote, out[3] = their summed durations in ms, out[4] = ms of the whole call.
+ * Returns the number written. */
 int p2e_last_phase_ms(p2e_ctx *ctx, float *out, int cap);
 
 /* ---- single generators (one reference run_once body each) ----------------------------------------- */

@@ -160,7 +160,7 @@ class Context:
     def last_phase_ms(self):
         buf = (C.c_float * 5)()
         self._L.p2e_last_phase_ms(self._h, buf, C.c_int(5))
-        return dict(zip(("scalar", "chains", "batch_inv", "expand", "total"), [float(x) for x in buf]))
+        return dict(zip(("scalar", "expand_launches", "expand_cols", "expand", "total"), [float(x) for x in buf]))
 
     # ---- allocation helpers -------------------------------------------------------------------------
     def _cols(self, k, n):
@@ -254,13 +254,14 @@ class Context:
         return packed, err, bad
 
     # ---- fused schedules -----------------------------------------------------------------------------
-    def ecdsa_verify_witness_batch(self, msg, r, s, pkx, pky, cols=None, err=None, valid=None):
-        """verify_secp256k1_message_circuit (gadgets/ecdsa.rs:30-53): (82615, n) Goldilocks columns."""
+    def ecdsa_verify_witness_batch(self, msg, r, s, pkx, pky, cols=None, err=None, valid=None, ld=None):
+        """verify_secp256k1_message_circuit (gadgets/ecdsa.rs:30-53): (82615, n) Goldilocks columns.
+        ``cols`` may be a column slice of a wider matrix: pass its row stride as ``ld``."""
         n = self._shape(msg)[0]
         cols = cols if cols is not None else self._cols(VERIFY_COLS, n)
         err = err if err is not None else self._vec(n, np.uint8)
         valid = valid if valid is not None else self._vec(n, np.uint8)
-        ld = self._shape(cols)[1]
+        ld = ld if ld is not None else self._shape(cols)[1]
         bad = self._check(self._L.p2e_ecdsa_verify_witness_batch(self._h, _ptr(msg), _ptr(r), _ptr(s), _ptr(pkx), _ptr(pky),
                                                                  _ptr(cols), C.c_size_t(n), C.c_size_t(ld), _ptr(err), _ptr(valid)))
         return cols, err, valid, bad

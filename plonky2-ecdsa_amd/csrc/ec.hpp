@@ -30,7 +30,7 @@ struct JacW {
 typedef ModP Fp;
 
 P2E_HD U256 fp_mul(const U256& a, const U256& b) { return fe_mul<Fp>(a, b); }
-P2E_HD U256 fp_sqr(const U256& a) { return fe_mul<Fp>(a, a); }
+P2E_HD U256 fp_sqr(const U256& a) { return fe_sqr<Fp>(a); }
 P2E_HD U256 fp_add(const U256& a, const U256& b) { return fe_add<Fp>(a, b); }
 P2E_HD U256 fp_sub(const U256& a, const U256& b) { return fe_sub<Fp>(a, b); }
 

@@ -79,11 +79,67 @@ struct ModN {  // Secp256K1Scalar
     }
 };
 
+// add / subtract with carry, 32-bit words.  clang lowers __builtin_addc/__builtin_subc chains to
+// v_add_co_u32 / v_addc_co_u32 (one instruction per word, carry in VCC, no operand shuffling).
+P2E_HD u32 addc32(u32 a, u32 b, u32& carry) {
+#if defined(__clang__)
+    unsigned co;
+    u32 r = __builtin_addc(a, b, carry, &co);
+    carry = co;
+    return r;
+#else
+    u64 t = (u64)a + b + carry;
+    carry = (u32)(t >> 32);
+    return (u32)t;
+#endif
+}
+P2E_HD u32 subb32(u32 a, u32 b, u32& borrow) {
+#if defined(__clang__)
+    unsigned bo;
+    u32 r = __builtin_subc(a, b, borrow, &bo);
+    borrow = bo;
+    return r;
+#else
+    u64 t = (u64)a - b - borrow;
+    borrow = (u32)(t >> 63);
+    return (u32)t;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // multi-word helpers (fully unrolled so the arrays live in VGPRs)
 // ------------------------------------------------------------------------------------------------
+// r[NA+NB] = a[NA] * b[NB].
+// Device form: product scanning (column by column) with a 96-bit accumulator; every partial product is
+//   v_mad_u64_u32 acc, vcc, a_i, b_j, acc      (64-bit accumulate, carry-out in VCC)
+//   v_addc_co_u32 acc2, vcc, 0, acc2, vcc      (third accumulator word)
+// i.e. two instructions per 32x32 product and no register shuffling (the compiler's own lowering of the
+// portable loop below spends ~4 extra v_mov/v_lshl_add_u64 per product building 64-bit operand pairs).
+// VCC written by the mad is consumed as carry-in by the very next instruction: the same back-to-back
+// pattern hipcc emits for 64-bit adds, no wait states needed.
 template <int NA, int NB>
-P2E_HD void mul_wide(const u32* a, const u32* b, u32* r) {  // r: NA+NB words
+P2E_HD void mul_wide(const u32* a, const u32* b, u32* r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 acc = 0;
+    u32 acc2 = 0;
+    P2E_UNROLL
+    for (int k = 0; k < NA + NB - 1; k++) {
+        P2E_UNROLL
+        for (int i = 0; i < NA; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < NB) {
+                asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+                    : "+v"(acc), "+v"(acc2)
+                    : "v"(a[i]), "v"(b[j])
+                    : "vcc");
+            }
+        }
+        r[k] = (u32)acc;
+        acc = (acc >> 32) | ((u64)acc2 << 32);
+        acc2 = 0;
+    }
+    r[NA + NB - 1] = (u32)acc;
+#else
     P2E_UNROLL
     for (int i = 0; i < NA + NB; i++) r[i] = 0;
     P2E_UNROLL
@@ -97,38 +153,71 @@ P2E_HD void mul_wide(const u32* a, const u32* b, u32* r) {  // r: NA+NB words
         }
         r[i + NB] = (u32)c;
     }
+#endif
+}
+
+// r[16] = a[8]^2: the 28 cross products once (96-bit column accumulator as in mul_wide), the whole
+// 512-bit cross sum doubled with one funnel-shift per word, then the 8 squares added on the even columns.
+// 36 v_mad_u64_u32 instead of 64.
+P2E_HD void sqr_wide8(const u32* a, u32* r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 x[16];
+    u64 acc = 0;
+    u32 acc2 = 0;
+    x[0] = 0;
+    P2E_UNROLL
+    for (int k = 1; k < 15; k++) {
+        P2E_UNROLL
+        for (int i = 0; i < 8; i++) {
+            const int j = k - i;
+            if (j > i && j < 8) {
+                asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+                    : "+v"(acc), "+v"(acc2)
+                    : "v"(a[i]), "v"(a[j])
+                    : "vcc");
+            }
+        }
+        x[k] = (u32)acc;
+        acc = (acc >> 32) | ((u64)acc2 << 32);
+        acc2 = 0;
+    }
+    x[15] = (u32)acc;
+    // double (the cross sum is < 2^511, nothing is shifted out)
+    P2E_UNROLL
+    for (int k = 15; k > 0; k--) x[k] = (x[k] << 1) | (x[k - 1] >> 31);
+    x[0] = 0;
+    // + sum_i a_i^2 * 2^(64 i)
+    u32 carry = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) {
+        u64 sq = (u64)a[i] * a[i];
+        r[2 * i] = addc32(x[2 * i], (u32)sq, carry);
+        r[2 * i + 1] = addc32(x[2 * i + 1], (u32)(sq >> 32), carry);
+    }
+#else
+    mul_wide<8, 8>(a, a, r);
+#endif
 }
 
 template <int N>
 P2E_HD u32 add_n(u32* r, const u32* a, const u32* b) {
-    u64 c = 0;
+    u32 c = 0;
     P2E_UNROLL
-    for (int i = 0; i < N; i++) {
-        c += (u64)a[i] + b[i];
-        r[i] = (u32)c;
-        c >>= 32;
-    }
-    return (u32)c;
+    for (int i = 0; i < N; i++) r[i] = addc32(a[i], b[i], c);
+    return c;
 }
 template <int N>
 P2E_HD u32 sub_n(u32* r, const u32* a, const u32* b) {  // returns borrow
     u32 br = 0;
     P2E_UNROLL
-    for (int i = 0; i < N; i++) {
-        u64 d = (u64)a[i] - b[i] - br;
-        r[i] = (u32)d;
-        br = (u32)(d >> 63);
-    }
+    for (int i = 0; i < N; i++) r[i] = subb32(a[i], b[i], br);
     return br;
 }
 template <int N>
 P2E_HD bool geq_n(const u32* a, const u32* b) {  // a >= b
     u32 br = 0;
     P2E_UNROLL
-    for (int i = 0; i < N; i++) {
-        u64 d = (u64)a[i] - b[i] - br;
-        br = (u32)(d >> 63);
-    }
+    for (int i = 0; i < N; i++) (void)subb32(a[i], b[i], br);
     return br == 0;
 }
 template <int N>
@@ -142,31 +231,20 @@ template <class MOD>
 P2E_HD bool geq_mod(const u32* a) {
     u32 br = 0;
     P2E_UNROLL
-    for (int i = 0; i < 8; i++) {
-        u64 d = (u64)a[i] - MOD::m(i) - br;
-        br = (u32)(d >> 63);
-    }
+    for (int i = 0; i < 8; i++) (void)subb32(a[i], MOD::m(i), br);
     return br == 0;
 }
 template <class MOD>
 P2E_HD void sub_mod_raw(u32* a) {  // a -= m
     u32 br = 0;
     P2E_UNROLL
-    for (int i = 0; i < 8; i++) {
-        u64 d = (u64)a[i] - MOD::m(i) - br;
-        a[i] = (u32)d;
-        br = (u32)(d >> 63);
-    }
+    for (int i = 0; i < 8; i++) a[i] = subb32(a[i], MOD::m(i), br);
 }
 template <class MOD>
 P2E_HD void add_mod_raw(u32* a) {  // a += m (mod 2^256)
-    u64 c = 0;
+    u32 c = 0;
     P2E_UNROLL
-    for (int i = 0; i < 8; i++) {
-        c += (u64)a[i] + MOD::m(i);
-        a[i] = (u32)c;
-        c >>= 32;
-    }
+    for (int i = 0; i < 8; i++) a[i] = addc32(a[i], MOD::m(i), c);
 }
 
 P2E_HD U256 u256_zero() {
@@ -234,6 +312,79 @@ P2E_HD void fold_step(const u32* hi, u32* lo, u32* hi_out, u32* q /*9 words*/) {
     }
 }
 
+// Specialised reduction for p = 2^256 - C, C = 2^32 + 977, of a 16-word product: hi*C is one
+// v_mad_u64_u32 chain by 977 plus a one-word shift, everything else is add-with-carry chains, and the
+// final canonicalisation is "add C, keep the sum if it carries out of 2^256" (r >= p <=> r + C >= 2^256).
+// Bounds as in DESIGN.md section 3.
+template <bool WANT_Q>
+P2E_HD void reduce_p16(const u32* prod, u32* r, u32* q /*9 or null*/) {
+    const u32* lo = prod;
+    const u32* hi = prod + 8;
+    // u[0..8] = hi * 977
+    u32 u[9];
+    u64 m = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) {
+        m = (u64)hi[i] * 977u + (m >> 32);
+        u[i] = (u32)m;
+    }
+    u[8] = (u32)(m >> 32);            // < 2^10
+    // t = lo + u[0..7] + (hi << 32)
+    u32 t[8];
+    u32 ca = 0, cb = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) t[i] = addc32(lo[i], u[i], ca);
+    P2E_UNROLL
+    for (int i = 1; i < 8; i++) t[i] = addc32(t[i], hi[i - 1], cb);
+    // h1 = u[8] + hi[7] + ca + cb   (< 2^33 + 2^10 + 2)
+    u32 ch = 0;
+    u32 h1lo = addc32(u[8], hi[7], ch);
+    u32 h1hi = ch;
+    ch = 0;
+    h1lo = addc32(h1lo, ca + cb, ch);
+    h1hi += ch;
+    // fold 2: t += h1 * 977 + (h1 << 32)
+    const u64 v = (u64)h1lo * 977u + ((u64)(h1hi * 977u) << 32);   // < 2^44
+    u32 c2 = 0;
+    t[0] = addc32(t[0], (u32)v, c2);
+    t[1] = addc32(t[1], (u32)(v >> 32), c2);
+    P2E_UNROLL
+    for (int i = 2; i < 8; i++) t[i] = addc32(t[i], 0u, c2);
+    u32 c2b = 0;
+    t[1] = addc32(t[1], h1lo, c2b);
+    t[2] = addc32(t[2], h1hi, c2b);
+    P2E_UNROLL
+    for (int i = 3; i < 8; i++) t[i] = addc32(t[i], 0u, c2b);
+    const u32 h2 = c2 + c2b;          // 0 or 1; if 1 then t < 2^78 and adding C cannot carry again
+    u32 c3 = 0;
+    t[0] = addc32(t[0], h2 ? 977u : 0u, c3);
+    t[1] = addc32(t[1], h2, c3);
+    P2E_UNROLL
+    for (int i = 2; i < 8; i++) t[i] = addc32(t[i], 0u, c3);
+    // canonical: w = t + C ; carry out <=> t >= p
+    u32 w[8];
+    u32 c4 = 0;
+    w[0] = addc32(t[0], 977u, c4);
+    w[1] = addc32(t[1], 1u, c4);
+    P2E_UNROLL
+    for (int i = 2; i < 8; i++) w[i] = addc32(t[i], 0u, c4);
+    const bool ge = c4 != 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) r[i] = ge ? w[i] : t[i];
+    if (WANT_Q) {   // q = hi + h1 + h2 + ge
+        u32 cq = 0;
+        q[0] = addc32(hi[0], h1lo, cq);
+        q[1] = addc32(hi[1], h1hi, cq);
+        P2E_UNROLL
+        for (int i = 2; i < 8; i++) q[i] = addc32(hi[i], 0u, cq);
+        q[8] = cq;
+        u32 cq2 = 0;
+        q[0] = addc32(q[0], h2 + (ge ? 1u : 0u), cq2);
+        P2E_UNROLL
+        for (int i = 1; i < 9; i++) q[i] = addc32(q[i], 0u, cq2);
+    }
+}
+
 // prod = hi:lo with NH high words.  Returns canonical r = prod mod m and (optionally) the exact
 // integer quotient q = floor(prod / m) in 9 words.  Fold schedule (hi word counts): p: NH,2,1 ;
 // n: NH,5,1,1 -- bounds derived in DESIGN.md "Field arithmetic".
@@ -272,6 +423,18 @@ P2E_HD void reduce_wide(const u32* prod /*8+NH*/, u32* r /*8*/, u32* q /*9 or nu
     for (int i = 0; i < 8; i++) r[i] = lo[i];
 }
 
+// 16-word product -> (r, q): specialised path for p, generic fold chain for n
+template <class MOD, bool WANT_Q>
+P2E_HD void reduce16(const u32* prod, u32* r, u32* q);
+template <>
+P2E_HD void reduce16<ModP, false>(const u32* prod, u32* r, u32* q) { reduce_p16<false>(prod, r, q); }
+template <>
+P2E_HD void reduce16<ModP, true>(const u32* prod, u32* r, u32* q) { reduce_p16<true>(prod, r, q); }
+template <>
+P2E_HD void reduce16<ModN, false>(const u32* prod, u32* r, u32* q) { reduce_wide<ModN, 8, false>(prod, r, q); }
+template <>
+P2E_HD void reduce16<ModN, true>(const u32* prod, u32* r, u32* q) { reduce_wide<ModN, 8, true>(prod, r, q); }
+
 // ------------------------------------------------------------------------------------------------
 // field ops on canonical values
 // ------------------------------------------------------------------------------------------------
@@ -283,7 +446,7 @@ P2E_HD_NOINLINE U256 fe_mul_call(U256 a, U256 b) {
     u32 prod[16];
     mul_wide<8, 8>(a.w, b.w, prod);
     U256 r;
-    reduce_wide<MOD, 8, false>(prod, r.w, nullptr);
+    reduce16<MOD, false>(prod, r.w, nullptr);
     return r;
 }
 template <class MOD>
@@ -291,8 +454,16 @@ P2E_HD U256 fe_mul(const U256& a, const U256& b) {
     return fe_mul_call<MOD>(a, b);
 }
 template <class MOD>
+P2E_HD_NOINLINE U256 fe_sqr_call(U256 a) {
+    u32 prod[16];
+    sqr_wide8(a.w, prod);
+    U256 r;
+    reduce16<MOD, false>(prod, r.w, nullptr);
+    return r;
+}
+template <class MOD>
 P2E_HD U256 fe_sqr(const U256& a) {
-    return fe_mul<MOD>(a, a);
+    return fe_sqr_call<MOD>(a);
 }
 template <class MOD>
 P2E_HD U256 fe_add(const U256& a, const U256& b) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -20,25 +21,53 @@ using namespace p2e;
 // kernels
 // ====================================================================================================
 constexpr int BS = 256;          // 4 waves per workgroup
-constexpr int BINV_CHUNK = 40;   // curve ops per Montgomery batch (one Fermat ladder each)
+constexpr int BINV_TARGET = 64;  // ~curve ops per Montgomery batch (one Fermat ladder each)
 
-__global__ __launch_bounds__(BS) void k_scalar(Program G, Buffers B) {
-    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
-    if (i < B.n) body_scalar(G, B, i);
+// Signature owned by this lane.  WIDE kernels (full workgroups only) give lanes l and l+32 of a wave
+// adjacent signatures so that column pairs can be written with 16-byte stores (PairEmit); the narrow
+// variants cover the ragged tail of the batch (first = first signature of the launch).
+template <bool WIDE>
+__device__ __forceinline__ size_t lane_sig(size_t first) {
+    unsigned t = threadIdx.x;
+    // (An XCD-contiguous remap of blockIdx -- every XCD owning one contiguous eighth of the batch -- was
+    // measured 2.5 % SLOWER on k_expand than the plain round-robin order and is not used.)
+    size_t base = first + (size_t)blockIdx.x * BS;
+    if (WIDE) return base + (t & ~63u) + 2u * (t & 31u) + ((t >> 5) & 1u);
+    return base + t;
 }
-__global__ __launch_bounds__(BS) void k_chains(Program G, Buffers B, int first_chain) {
-    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
-    if (i < B.n) body_chain(G, B, i, first_chain + (int)blockIdx.y);
+template <bool WIDE>
+__global__ __launch_bounds__(BS) void k_scalar(Program G, Buffers B, size_t first) {
+    size_t i = lane_sig<WIDE>(first);
+    if (WIDE) {
+        body_scalar<PairEmit>(G, B, i);
+    } else if (i < B.n) {
+        body_scalar<Emit>(G, B, i);
+    }
 }
-__global__ __launch_bounds__(BS) void k_batch_inv(Program G, Buffers B) {
+// ops [lo, hi) of a chain, sequential per lane
+__global__ __launch_bounds__(BS) void k_chains(Program G, Buffers B, int lo, int hi) {
+    // the chain is the critical path of the whole call and shares its SIMD with phase B/C waves of
+    // earlier pieces: win every issue arbitration against them
+    __builtin_amdgcn_s_setprio(3);
     size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
-    int t0 = (int)blockIdx.y * BINV_CHUNK;
-    int t1 = t0 + BINV_CHUNK < G.num_ops ? t0 + BINV_CHUNK : G.num_ops;
+    if (i < B.n) body_chain_range(G, B, i, lo, hi);
+}
+// ops [lo, hi) in chunks of ch: blockIdx.y = chunk
+__global__ __launch_bounds__(BS) void k_batch_inv(Program G, Buffers B, int lo, int hi, int ch) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    int t0 = lo + (int)blockIdx.y * ch;
+    int t1 = t0 + ch < hi ? t0 + ch : hi;
     if (i < B.n) body_batch_inv(G, B, i, t0, t1);
 }
-__global__ __launch_bounds__(BS) void k_expand(Program G, Buffers B) {
-    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
-    if (i < B.n) body_expand(G, B, i, (int)blockIdx.y);
+// op lo + blockIdx.y
+template <bool WIDE>
+__global__ __launch_bounds__(BS) void k_expand(Program G, Buffers B, int lo, size_t first) {
+    size_t i = lane_sig<WIDE>(first);
+    if (WIDE) {
+        body_expand<PairEmit>(G, B, i, lo + (int)blockIdx.y);
+    } else if (i < B.n) {
+        body_expand<Emit>(G, B, i, lo + (int)blockIdx.y);
+    }
 }
 // err words -> caller's err bytes, valid bytes, flagged count
 __global__ __launch_bounds__(BS) void k_finalize(const u32* err32, const uint8_t* valid8, uint8_t* err_out,
@@ -184,6 +213,7 @@ static void set_error(const std::string& s) { g_last_error = s; }
 struct DeviceProgram {
     Program prog;
     OpDesc* d_ops = nullptr;
+    std::vector<OpDesc> h_ops;
     std::vector<host::GenOp> gens;
 };
 
@@ -192,6 +222,20 @@ struct p2e_ctx {
     unsigned flags = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // The Jacobian chains are latency-bound (one wave per SIMD, strictly sequential) and leave most of the
+    // ALU and all of the HBM bandwidth idle; the witness expansion is HBM-bound.  So the chains run on
+    // their own high-priority streams, cut into pieces, and phases B/C of every finished piece run on the
+    // caller's stream underneath the following pieces.
+    static constexpr int MAX_PIECES = 16;
+    static constexpr int MAX_SEG = 2 * MAX_PIECES + 2;
+    hipStream_t st_msm = nullptr, st_fixed = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_fixed = nullptr, ev_piece[MAX_SEG] = {}, ev_binv[MAX_SEG] = {};
+    hipEvent_t ev_c0[MAX_SEG] = {}, ev_c1[MAX_SEG] = {};   // around every k_expand launch
+    int n_expand = 0;
+    double expand_cols[MAX_SEG] = {};
+    float expand_ms_sum = 0.f;
+    double expand_cols_sum = 0.0;
+    int msm_pieces = 6, fixed_pieces = 1;
     Aff* d_cpts = nullptr;
     Aff* d_fbtab = nullptr;
     DeviceProgram progs[2];
@@ -229,7 +273,7 @@ static std::vector<OpDesc> host_ops(int program) {
 }
 
 struct ScratchLayout {
-    size_t px, py, pz, pw, pref, dig4, dig2, dyn, err32, valid8, total;
+    size_t px, py, pz, pw, pref, ax, ay, dig4, dig2, dyn, err32, valid8, total;
 };
 static ScratchLayout scratch_layout(const Program& G, size_t n) {
     ScratchLayout L{};
@@ -241,9 +285,11 @@ static ScratchLayout scratch_layout(const Program& G, size_t n) {
     };
     L.px = take((size_t)G.num_slots * n * 32);
     L.py = take((size_t)G.num_slots * n * 32);
-    L.pz = take((size_t)G.num_ops * n * 32);
+    L.pz = take((size_t)G.num_slots * n * 32);
     L.pw = take((size_t)G.num_ops * n * 32);
     L.pref = take((size_t)G.num_ops * n * 32);
+    L.ax = take((size_t)G.num_slots * n * 32);
+    L.ay = take((size_t)G.num_slots * n * 32);
     L.dig4 = take((size_t)FB_WINDOWS * n);
     L.dig2 = take((size_t)MSM_DIGITS * n);
     L.dyn = take((size_t)G.num_cadd * n * 2);
@@ -289,12 +335,31 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     for (int p = 0; p < 2; p++) {
         c->progs[p].prog = host_program(p).prog;
         std::vector<OpDesc> ops = host_ops(p);
+        c->progs[p].h_ops = ops;
         HIP_TRY(hipMalloc(&c->progs[p].d_ops, sizeof(OpDesc) * ops.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_ops, ops.data(), sizeof(OpDesc) * ops.size(), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMalloc(&c->d_counter, sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(&c->h_counter, sizeof(unsigned long long)));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    int prio_lo = 0, prio_hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->st_msm, hipStreamNonBlocking, prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->st_fixed, hipStreamNonBlocking, prio_hi));
+    for (auto& e : c->ev_binv) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fixed, hipEventDisableTiming));
+    for (auto& e : c->ev_piece) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : c->ev_c0) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : c->ev_c1) HIP_TRY(hipEventCreate(&e));
+    if (const char* env = getenv("P2E_MSM_PIECES")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->msm_pieces = v;
+    }
+    if (const char* env = getenv("P2E_FIXED_PIECES")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->fixed_pieces = v;
+    }
     *out = c;
     return 0;
 }
@@ -311,6 +376,21 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
     (void)hipHostFree(c->h_counter);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_binv)
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {c->st_msm, c->st_fixed})
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    for (hipEvent_t e : {c->ev_fork, c->ev_fixed})
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_piece)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_c0)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_c1)
+        if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -319,8 +399,19 @@ extern "C" int p2e_sync(p2e_ctx* c) {
     if (!c) return P2E_E_INVALID;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->have_phases) {
-        for (int k = 0; k < 4; k++) (void)hipEventElapsedTime(&c->phase_ms[k], c->ev[k], c->ev[k + 1]);
-        (void)hipEventElapsedTime(&c->phase_ms[4], c->ev[0], c->ev[4]);
+        (void)hipEventElapsedTime(&c->phase_ms[0], c->ev[0], c->ev[1]);   // scalar kernel
+        (void)hipEventElapsedTime(&c->phase_ms[4], c->ev[0], c->ev[5]);   // whole call
+        c->expand_ms_sum = 0.f;
+        c->expand_cols_sum = 0.0;
+        for (int k = 0; k < c->n_expand; k++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, c->ev_c0[k], c->ev_c1[k]);
+            c->expand_ms_sum += ms;
+            c->expand_cols_sum += c->expand_cols[k];
+        }
+        c->phase_ms[1] = (float)c->n_expand;         // number of k_expand launches
+        c->phase_ms[2] = (float)c->expand_cols_sum;  // columns they wrote (per signature)
+        c->phase_ms[3] = c->expand_ms_sum;           // their summed durations
     }
     return (int)*c->h_counter;
 }
@@ -603,6 +694,8 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     B.PZ = (U256*)(base + L.pz);
     B.PW = (U256*)(base + L.pw);
     B.PREF = (U256*)(base + L.pref);
+    B.AX = (U256*)(base + L.ax);
+    B.AY = (U256*)(base + L.ay);
     B.dig4 = (uint8_t*)(base + L.dig4);
     B.dig2 = (uint8_t*)(base + L.dig2);
     B.dyn = (uint16_t*)(base + L.dyn);
@@ -611,19 +704,96 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     B.ops = DP.d_ops;
     ZERO_COUNTER(c);
     unsigned gx = (unsigned)((n + BS - 1) / BS);
+    c->n_expand = 0;
+    // 16-byte column stores need full workgroups, an even column stride and a 16-byte aligned matrix
+    const bool wide_ok = (ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(cols) & 15) == 0) && !getenv("P2E_NARROW_STORES");
+    const size_t n_wide = wide_ok ? (n / BS) * BS : 0;
+    const unsigned gx_wide = (unsigned)(n_wide / BS);
+    const unsigned gx_tail = (unsigned)((n - n_wide + BS - 1) / BS);
+    // ---- launch plan ------------------------------------------------------------------------------------
+    // chains (latency-bound, sequential) : their own high-priority streams, cut into pieces
+    // phase B of a piece                 : st_binv, as soon as the piece's chain kernel is done (ALU-bound)
+    // phase C of a piece                 : the caller's stream, after its phase B (HBM-bound)
+    // so that the HBM-bound expansion of finished pieces hides the chains and inversions of later ones.
+    struct Seg {
+        int lo, hi, order;   // ops, readiness estimate (ops walked on its chain before it completes)
+        hipStream_t chain_stream;
+        bool final_after;    // append the final add (needs the fixed-base chain) to this piece
+    };
+    Seg segs[p2e_ctx::MAX_SEG];
+    int ns = 0;
+    const bool verify = G.num_chains == 3;
+    auto cut = [&](int lo, int hi, int pieces, hipStream_t st, bool small_first) {
+        if (pieces > hi - lo) pieces = hi - lo;
+        int a = lo;
+        for (int k = 0; k < pieces; k++) {
+            int rem = pieces - k;
+            int len = (hi - a + rem - 1) / rem;
+            if (small_first && k == 0 && pieces > 1 && len > 23) len = 23;   // MSM table build: first C early
+            segs[ns++] = Seg{a, a + len, a + len - lo, st, false};
+            a += len;
+        }
+    };
+    if (verify) cut(G.chain_begin[1], G.chain_end[1], c->fixed_pieces, c->st_fixed, false);
+    int first_msm = ns;
+    cut(G.chain_begin[0], G.chain_end[0], c->msm_pieces, c->st_msm, true);
+    if (verify) segs[ns - 1].final_after = true;
+
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(k_scalar, dim3(gx), dim3(BS), 0, c->stream, G, B);
+    if (gx_wide) hipLaunchKernelGGL(k_scalar<true>, dim3(gx_wide), dim3(BS), 0, c->stream, G, B, (size_t)0);
+    if (gx_tail) hipLaunchKernelGGL(k_scalar<false>, dim3(gx_tail), dim3(BS), 0, c->stream, G, B, n_wide);
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    for (int st = 0; st < G.num_stages; st++) {
-        int f = G.stage_first_chain[st], l = G.stage_first_chain[st + 1];
-        hipLaunchKernelGGL(k_chains, dim3(gx, (unsigned)(l - f)), dim3(BS), 0, c->stream, G, B, f);
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->st_msm, c->ev_fork, 0));
+    HIP_TRY(hipStreamWaitEvent(c->st_fixed, c->ev_fork, 0));
+    // chains
+    for (int k = 0; k < ns; k++) {
+        Seg& sg = segs[k];
+        hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, sg.hi);
+        if (verify && k == first_msm - 1) HIP_TRY(hipEventRecord(c->ev_fixed, c->st_fixed));
+        if (sg.final_after) {
+            HIP_TRY(hipStreamWaitEvent(c->st_msm, c->ev_fixed, 0));
+            hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, c->st_msm, G, B, G.chain_begin[2], G.chain_end[2]);
+            sg.hi = G.chain_end[2];
+        }
+        HIP_TRY(hipEventRecord(c->ev_piece[k], sg.chain_stream));
     }
-    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    unsigned chunks = (unsigned)((G.num_ops + BINV_CHUNK - 1) / BINV_CHUNK);
-    hipLaunchKernelGGL(k_batch_inv, dim3(gx, chunks), dim3(BS), 0, c->stream, G, B);
-    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    hipLaunchKernelGGL(k_expand, dim3(gx, (unsigned)G.num_ops), dim3(BS), 0, c->stream, G, B);
-    HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+    // order of phases B / C: by readiness
+    int order[p2e_ctx::MAX_SEG];
+    for (int k = 0; k < ns; k++) order[k] = k;
+    for (int a = 1; a < ns; a++)
+        for (int b = a; b > 0 && segs[order[b]].order < segs[order[b - 1]].order; b--) {
+            int t = order[b];
+            order[b] = order[b - 1];
+            order[b - 1] = t;
+        }
+    c->n_expand = 0;
+    for (int q = 0; q < ns; q++) {
+        const int k = order[q];
+        const Seg& sg = segs[k];
+        unsigned nch = (unsigned)((sg.hi - sg.lo + BINV_TARGET - 1) / BINV_TARGET);
+        int ch = (sg.hi - sg.lo + (int)nch - 1) / (int)nch;
+        // HIP multiplexes streams onto a few hardware queues (4 by default) and kernels of one queue run
+        // in order: a dedicated inversion stream ended up sharing the caller's queue and serialised B
+        // with C.  The fixed-base chain's stream is idle after its first ~1 ms, so phase B lives there.
+        hipStream_t st_b = c->st_fixed;
+        HIP_TRY(hipStreamWaitEvent(st_b, c->ev_piece[k], 0));
+        hipLaunchKernelGGL(k_batch_inv, dim3(gx, nch), dim3(BS), 0, st_b, G, B, sg.lo, sg.hi, ch);
+        HIP_TRY(hipEventRecord(c->ev_binv[k], st_b));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_binv[k], 0));
+        int e = c->n_expand++;
+        HIP_TRY(hipEventRecord(c->ev_c0[e], c->stream));
+        if (gx_wide)
+            hipLaunchKernelGGL(k_expand<true>, dim3(gx_wide, (unsigned)(sg.hi - sg.lo)), dim3(BS), 0, c->stream, G, B, sg.lo, (size_t)0);
+        if (gx_tail)
+            hipLaunchKernelGGL(k_expand<false>, dim3(gx_tail, (unsigned)(sg.hi - sg.lo)), dim3(BS), 0, c->stream, G, B, sg.lo, n_wide);
+        HIP_TRY(hipEventRecord(c->ev_c1[e], c->stream));
+        double cols_written = 0;
+        for (int t = sg.lo; t < sg.hi; t++)
+            cols_written += DP.h_ops[t].kind == OP_DBL ? COLS_DBL : DP.h_ops[t].kind == OP_CADD ? COLS_CADD : COLS_ADD;
+        c->expand_cols[e] = cols_written;
+    }
+    HIP_TRY(hipEventRecord(c->ev[5], c->stream));
     hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, B.err, B.valid, err, valid, n, c->d_counter);
     c->have_phases = true;
     return S.done(finish_call(c));

@@ -55,9 +55,8 @@ struct Program {
     int32_t num_cols;
     ScalarCols sc;
     u32 msm_tab[16];        // refs of precomputation[0..15]
-    // phase A stages: chains of consecutive op ranges
-    int32_t num_stages;
-    int32_t stage_first_chain[4];
+    // sequentially dependent op ranges ("chains").  verify: 0 = MSM chain, 1 = fixed-base chain (independent of
+    // chain 0, own stream), 2 = final add (needs both).  glv_mul: 0 = the whole schedule.
     int32_t num_chains;
     int32_t chain_begin[4], chain_end[4];
 };
@@ -69,8 +68,8 @@ struct Buffers {
     size_t ld, n;
     u32* err;        // per-element error bits (never null; OR-ed atomically by phases B and C)
     uint8_t* valid;  // per-element "all connect constraints hold" (never null)
-    // scratch, [slot][n]
-    U256 *PX, *PY, *PZ, *PW, *PREF;
+    // scratch, [slot][n]: Jacobian points + numerator of v^-1 (phase A), prefix products and affine points (phase B)
+    U256 *PX, *PY, *PZ, *PW, *PREF, *AX, *AY;
     uint8_t* dig4;   // [66][n]
     uint8_t* dig2;   // [73][n]   4*m_d + n_d
     uint16_t* dyn;   // [num_cadd][n]
@@ -109,14 +108,9 @@ P2E_HD u32 digit_of(const U256& v, int t) {
     return (v.w[bit >> 5] >> (bit & 31)) & ((1u << WB) - 1);  // WB divides 32: never straddles
 }
 
-P2E_HD Emit emit_at(const Buffers& B, size_t i, u32 col) {
-    Emit e;
-    e.p = B.out + (size_t)col * B.ld + i;
-    e.ld = B.ld;
-    return e;
-}
 
 // ---- phase S --------------------------------------------------------------------------------------------
+template <class E>
 P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
     uint8_t err = 0;
     bool ok = true;
@@ -125,7 +119,7 @@ P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
     if (G.full_verify) {
         U256 msg = load_packed(B.msg, i), r = load_packed(B.r, i), s = load_packed(B.s, i);
         {  // curve_assert_valid gadgets/curve.rs:123-135
-            Emit e = emit_at(B, i, (u32)G.sc.assert_valid);
+            E e = E::at(B.out, B.ld, i, (u32)G.sc.assert_valid);
             U256 y2 = wit_mul<ModP>(e, py, py, err);
             U256 x2 = wit_mul<ModP>(e, px, px, err);
             U256 x3 = wit_mul<ModP>(e, x2, px, err);
@@ -133,11 +127,13 @@ P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
             U256 axb = wit_add<ModP>(e, ax, u256_small(7));
             U256 rhs = wit_add<ModP>(e, x3, axb);
             ok = ok && u256_eq(y2, rhs);
+            e.flush();
         }
-        Emit e = emit_at(B, i, (u32)G.sc.inv_s);
+        E e = E::at(B.out, B.ld, i, (u32)G.sc.inv_s);
         U256 c = wit_inv<ModN>(e, s, err);        // gadgets/ecdsa.rs:40
         U256 u1 = wit_mul<ModN>(e, msg, c, err);  // :41
         k = wit_mul<ModN>(e, r, c, err);          // :42
+        e.flush();
         for (int w = 0; w < FB_WINDOWS; w++) B.dig4[(size_t)w * B.n + i] = (uint8_t)digit_of<4>(u1, w);
     } else {
         k = load_packed(B.msg, i);
@@ -145,7 +141,7 @@ P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
     // decompose_secp256k1_scalar gadgets/glv.rs:53-85
     GlvOut g = glv_decompose(k);
     {
-        Emit e = emit_at(B, i, (u32)G.sc.glv);
+        E e = E::at(B.out, B.ld, i, (u32)G.sc.glv);
         u32 l[NL];
         split29(g.k1, l);
         emit_limbs(e, l, 5);
@@ -171,6 +167,7 @@ P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
         sb = wit_add<ModN>(e, sb, k1r);
         // connect_nonnative(should_be_k, k): limb-wise equality with the (raw) k target
         ok = ok && u256_eq(sb, k);
+        e.flush();
     }
     for (int d = 0; d < MSM_DIGITS; d++)
         B.dig2[(size_t)d * B.n + i] = (uint8_t)(4 * digit_of<2>(g.k2, d) + digit_of<2>(g.k1, d));
@@ -185,17 +182,25 @@ P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
             beta.w[2 * q + 1] = (u32)(bv[q] >> 32);
         }
     }
-    Emit e1 = emit_at(B, i, (u32)G.sc.beta_x);
+    E e1 = E::at(B.out, B.ld, i, (u32)G.sc.beta_x);
     U256 bx = wit_mul<ModP>(e1, beta, px, err);
-    Emit e2 = emit_at(B, i, (u32)G.sc.neg_p);
+    e1.flush();
+    E e2 = E::at(B.out, B.ld, i, (u32)G.sc.neg_p);
     U256 y1 = wit_cond_neg<ModP>(e2, py, g.n1);
-    Emit e3 = emit_at(B, i, (u32)G.sc.neg_sp);
+    e2.flush();
+    E e3 = E::at(B.out, B.ld, i, (u32)G.sc.neg_sp);
     U256 y2 = wit_cond_neg<ModP>(e3, py, g.n2);
+    e3.flush();
     size_t sp = (size_t)G.slot_p * B.n + i, ssp = (size_t)G.slot_sp * B.n + i;
-    B.PX[sp] = fe_canon<ModP>(px);  // only ever consumed through canonicalising generators
+    U256 pxc = fe_canon<ModP>(px);  // only ever consumed through canonicalising generators
+    B.PX[sp] = pxc;
     B.PY[sp] = y1;
     B.PX[ssp] = bx;
     B.PY[ssp] = y2;
+    B.AX[sp] = pxc;
+    B.AY[sp] = y1;
+    B.AX[ssp] = bx;
+    B.AY[ssp] = y2;
     B.err[i] = err;
     B.valid[i] = ok ? 1 : 0;
 }
@@ -218,8 +223,8 @@ P2E_HD Aff load_aff_src(const Buffers& B, size_t i, uint16_t src) {
     if (src & DYN_CONST_BIT) {
         a = B.cpts[src & 0x7FFF];
     } else {
-        a.x = B.PX[(size_t)src * B.n + i];
-        a.y = B.PY[(size_t)src * B.n + i];
+        a.x = B.AX[(size_t)src * B.n + i];
+        a.y = B.AY[(size_t)src * B.n + i];
     }
     return a;
 }
@@ -279,11 +284,14 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t) {
     B.PZ[o] = res.p.Z;
     B.PW[o] = res.W;
 }
-P2E_HD void body_chain(const Program& G, const Buffers& B, size_t i, int chain) {
-    for (int t = G.chain_begin[chain]; t < G.chain_end[chain]; t++) body_chain_op(G, B, i, t);
+// ops [lo, hi) of one chain, in order (the range may be a piece of a chain: all state lives in scratch)
+P2E_HD void body_chain_range(const Program& G, const Buffers& B, size_t i, int lo, int hi) {
+    for (int t = lo; t < hi; t++) body_chain_op(G, B, i, t);
 }
 
 // ---- phase B: Montgomery batch inversion of Z over ops [t0, t1) of one signature ------------------------
+// Reads the Jacobian results (left intact: later pieces of the chain still consume them), writes the
+// affine points to AX/AY and v^-1 over W.
 P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0, int t1) {
     (void)G;
     uint8_t err = 0;
@@ -294,7 +302,6 @@ P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0,
         if (u256_is_zero(z)) {  // reference: inverse() of zero panics (gadgets/nonnative.rs:863)
             err |= ERR_INVERSE_OF_ZERO;
             z = u256_small(1);
-            B.PZ[o] = z;
         }
         B.PREF[o] = acc;
         acc = fp_mul(acc, z);
@@ -303,12 +310,13 @@ P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0,
     for (int t = t1 - 1; t >= t0; t--) {
         size_t o = (size_t)t * B.n + i;
         U256 z = B.PZ[o];
+        if (u256_is_zero(z)) z = u256_small(1);
         U256 zi = fp_mul(inv, B.PREF[o]);
         inv = fp_mul(inv, z);
         U256 zi2 = fp_sqr(zi);
         U256 zi3 = fp_mul(zi2, zi);
-        B.PX[o] = fp_mul(B.PX[o], zi2);
-        B.PY[o] = fp_mul(B.PY[o], zi3);
+        B.AX[o] = fp_mul(B.PX[o], zi2);
+        B.AY[o] = fp_mul(B.PY[o], zi3);
         B.PW[o] = fp_mul(B.PW[o], zi);  // v^-1 of op t
     }
     if (err) err_or(&B.err[i], err);
@@ -349,10 +357,11 @@ P2E_HD Aff wit_curve_double(E& e, const Aff& p, const U256& vinv, uint8_t& err) 
     r.y = wit_sub<ModP>(e, lx, p.y);
     return r;
 }
+template <class E>
 P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t) {
     const OpDesc op = B.ops[t];
     uint8_t err = 0;
-    Emit e = emit_at(B, i, op.col);
+    E e = E::at(B.out, B.ld, i, op.col);
     U256 vinv = B.PW[(size_t)t * B.n + i];
     Aff p1 = load_aff_src(B, i, resolve_src(G, B, i, op.ref1));
     if (op.kind == OP_DBL) {
@@ -377,6 +386,7 @@ P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t) {
             if (!u256_eq(s.x, r)) B.valid[i] = 0;
         }
     }
+    e.flush();
     if (err) err_or(&B.err[i], err);
 }
 

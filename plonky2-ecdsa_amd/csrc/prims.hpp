@@ -12,6 +12,8 @@ struct ArrEmit {
     u64* a;
     int k;
     P2E_HD void put(u64 v) { a[k++] = v; }
+    P2E_HD void put_at(int d, u64 v) { a[k + d] = v; }
+    P2E_HD void skip(int d) { k += d; }
 };
 
 // sum limb_k * 2^(29k) for arbitrary 64-bit limbs; false if the value is >= 2^256

@@ -202,17 +202,13 @@ public:
             curve_add(point1, point2, true);
             ops.back().flags |= F_CHECK_R;
         }
-        prog.num_stages = 2;
         prog.num_chains = 3;
-        prog.chain_begin[0] = c1;  // longest chain first
+        prog.chain_begin[0] = c1;
         prog.chain_end[0] = c2;
         prog.chain_begin[1] = c0;
         prog.chain_end[1] = c1;
         prog.chain_begin[2] = c2;
         prog.chain_end[2] = (int)ops.size();
-        prog.stage_first_chain[0] = 0;
-        prog.stage_first_chain[1] = 2;
-        prog.stage_first_chain[2] = 3;
         finish();
     }
     // glv_mul(p, k) alone (BASELINE config 3)
@@ -220,12 +216,9 @@ public:
         prog.full_verify = 0;
         prog.sc.assert_valid = prog.sc.inv_s = prog.sc.u1 = prog.sc.u2 = -1;
         glv_mul();
-        prog.num_stages = 1;
         prog.num_chains = 1;
         prog.chain_begin[0] = 0;
         prog.chain_end[0] = (int)ops.size();
-        prog.stage_first_chain[0] = 0;
-        prog.stage_first_chain[1] = 1;
         finish();
     }
 

@@ -17,19 +17,100 @@
 
 namespace p2e {
 
-// cursor over one signature's column of the output matrix
+// cursor over one signature's column of the output matrix: plain 8-byte stores (one per lane per column)
 struct Emit {
     u64* p;      // &out[col * ld + sig]
     size_t ld;   // column stride in elements
+    P2E_HD static Emit at(u64* out, size_t ld_, size_t sig, u32 col) {
+        Emit e;
+        e.p = out + (size_t)col * ld_ + sig;
+        e.ld = ld_;
+        return e;
+    }
     P2E_HD void put(u64 v) {
         *p = v;
         p += ld;
     }
+    // store k columns ahead of the cursor without moving it
+    P2E_HD void put_at(int k, u64 v) { p[(size_t)k * ld] = v; }
+    P2E_HD void skip(int k) { p += (size_t)k * ld; }
+    P2E_HD void flush() {}
 };
-// null sink with the same interface (used where only the value is wanted)
-struct NoEmit {
-    P2E_HD void put(u64) {}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Same interface, 16-byte stores.  The column stores of the fused kernels are store-ISSUE bound with
+// 8 B per lane (MI355X_MICROARCH.md "store tail": ~7 B/clk/CU), so two consecutive columns c, c+1 are
+// written with ONE global_store_dwordx4 per lane: the wave's lanes l and l+32 own ADJACENT signatures
+// (sig = base + 2*(l & 31) + (l >> 5)), a v_permlane32_swap pair exchanges "my column-c+1 value" of the
+// lower half with "my column-c value" of the upper half, after which lower lanes hold column c of
+// signatures (2l, 2l+1) and upper lanes column c+1 of the same two signatures: 16 contiguous bytes each,
+// 512 contiguous bytes per half-wave.  Requires EXEC = all ones (full waves), ld even, 16-byte aligned
+// base; the launcher falls back to Emit otherwise.  All bookkeeping below (column counters, "have a
+// pending value") is compile-time after inlining: every put sequence is static.
+struct PairEmit {
+    u64* base;    // &out[col0 * ld]
+    size_t ld;
+    size_t sig;   // this lane's signature
+    u32 upper;    // lane >> 5
+    int col;      // cursor, relative to col0
+    bool have, have2;
+    u64 pend, pend2;
+    int pcol, pcol2;
+    P2E_HD static PairEmit at(u64* out, size_t ld_, size_t sig_, u32 col0) {
+        PairEmit e;
+        e.base = out + (size_t)col0 * ld_;
+        e.ld = ld_;
+        e.sig = sig_;
+        e.upper = (u32)(sig_ & 1);   // the lane mapping makes the signature's parity the half-wave index
+        e.col = 0;
+        e.have = e.have2 = false;
+        e.pend = e.pend2 = 0;
+        e.pcol = e.pcol2 = 0;
+        return e;
+    }
+    P2E_HD void store_single(int c, u64 v) { base[(size_t)c * ld + sig] = v; }
+    P2E_HD void store_pair(int c, u64 a, u64 b) {   // a: my value of column c, b: of column c + 1
+        u32 ax = (u32)a, ay = (u32)(a >> 32), bx = (u32)b, by = (u32)(b >> 32);
+        auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+        uint4 o = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        u64* dst = base + (size_t)(c + (int)upper) * ld + (sig - upper);
+        *reinterpret_cast<uint4*>(dst) = o;
+    }
+    P2E_HD void put(u64 v) {
+        if (have && pcol + 1 == col) {
+            store_pair(pcol, pend, v);
+            have = false;
+        } else {
+            if (have) store_single(pcol, pend);
+            pend = v;
+            pcol = col;
+            have = true;
+        }
+        col++;
+    }
+    P2E_HD void put_at(int k, u64 v) {
+        const int c = col + k;
+        if (have2 && pcol2 + 1 == c) {
+            store_pair(pcol2, pend2, v);
+            have2 = false;
+        } else {
+            if (have2) store_single(pcol2, pend2);
+            pend2 = v;
+            pcol2 = c;
+            have2 = true;
+        }
+    }
+    P2E_HD void skip(int k) { col += k; }
+    P2E_HD void flush() {
+        if (have) store_single(pcol, pend);
+        if (have2) store_single(pcol2, pend2);
+        have = have2 = false;
+    }
 };
+#else
+typedef Emit PairEmit;   // host passes only parse the kernels that name it
+#endif
 
 template <class E>
 P2E_HD void emit_limbs(E& e, const u32* l, int n) {
@@ -125,7 +206,7 @@ P2E_HD void wit_inv_given(E& e, const U256& x_raw, const U256& inv, uint8_t& err
     if (u256_is_zero(x)) err |= ERR_INVERSE_OF_ZERO;
     u32 prod[16], q[9], r[8];
     mul_wide<8, 8>(x.w, inv.w, prod);
-    reduce_wide<MOD, 8, true>(prod, r, q);
+    reduce16<MOD, true>(prod, r, q);
     emit_u256(e, inv);
     u32 ql[NL];
     P2E_UNROLL
@@ -177,7 +258,8 @@ P2E_HD void emit_mul_rows(E& e, const u32* x29, const u32* y29, const u32* q29, 
     emit_limbs(e, r29, NL);
     emit_limbs(e, q29, NL);
     i64 last = 0;
-    u64 bvals[2 * NL - 2];
+    // check_sum[i] goes to the cursor, the carry b[i] 17 columns further (CheckSumGate row): stored as soon
+    // as it is known, so nothing has to stay live across the 17 convolution columns
     P2E_UNROLL
     for (int i = 0; i < 2 * NL - 1; i++) {
         u64 xy = 0;
@@ -193,12 +275,11 @@ P2E_HD void emit_mul_rows(E& e, const u32* x29, const u32* y29, const u32* q29, 
             i64 bi = t >> BITS;  // exact: the integer is a multiple of 2^29 whenever q, r are right
             u64 bo = (u64)(bi + ((i64)1 << 33));
             if (bo >> 34) err |= ERR_CARRY_RANGE;
-            bvals[i] = bo;
+            e.put_at(2 * NL - 2, bo);   // cursor already advanced past check_sum[i]: b[i] is 16 columns ahead
             last = bi;
         }
     }
-    P2E_UNROLL
-    for (int i = 0; i < 2 * NL - 2; i++) e.put(bvals[i]);
+    e.skip(2 * NL - 2);
 }
 
 // x, y: the values carried by the two operands' limbs (used RAW: reference quirk Q3), < 2^256
@@ -207,7 +288,7 @@ P2E_HD U256 wit_mul(E& e, const U256& x, const U256& y, uint8_t& err) {
     u32 prod[16], q[9];
     U256 r;
     mul_wide<8, 8>(x.w, y.w, prod);
-    reduce_wide<MOD, 8, true>(prod, r.w, q);
+    reduce16<MOD, true>(prod, r.w, q);
     u32 x29[NL], y29[NL], q29[NL], r29[NL];
     split29(x, x29);
     split29(y, y29);

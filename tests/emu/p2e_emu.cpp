@@ -22,8 +22,8 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
         sb.glv_mul_circuit();
     const Program& G = sb.prog;
     const host::Consts& C = host::consts();
-    std::vector<U256> PX((size_t)G.num_slots * n), PY((size_t)G.num_slots * n), PZ((size_t)G.num_ops * n),
-        PW((size_t)G.num_ops * n), PREF((size_t)G.num_ops * n);
+    std::vector<U256> PX((size_t)G.num_slots * n), PY((size_t)G.num_slots * n), PZ((size_t)G.num_slots * n),
+        PW((size_t)G.num_ops * n), PREF((size_t)G.num_ops * n), AX((size_t)G.num_slots * n), AY((size_t)G.num_slots * n);
     std::vector<uint8_t> dig4((size_t)FB_WINDOWS * n), dig2((size_t)MSM_DIGITS * n), valid8(n);
     std::vector<uint16_t> dyn((size_t)G.num_cadd * n);
     std::vector<u32> err32(n);
@@ -32,25 +32,49 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     B.out = cols; B.ld = ld; B.n = n;
     B.err = err32.data(); B.valid = valid8.data();
     B.PX = PX.data(); B.PY = PY.data(); B.PZ = PZ.data(); B.PW = PW.data(); B.PREF = PREF.data();
+    B.AX = AX.data(); B.AY = AY.data();
     B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data();
     B.cpts = C.cpts; B.fbtab = C.fbtab.data(); B.ops = sb.ops.data();
 #pragma omp parallel for
-    for (long long i = 0; i < (long long)n; i++) body_scalar(G, B, (size_t)i);
-    for (int st = 0; st < G.num_stages; st++) {
-        int f = G.stage_first_chain[st], l = G.stage_first_chain[st + 1];
-#pragma omp parallel for collapse(2)
-        for (int c = f; c < l; c++)
-            for (long long i = 0; i < (long long)n; i++) body_chain(G, B, (size_t)i, c);
-    }
-    int chunks = (G.num_ops + chunk - 1) / chunk;
-    for (int c = 0; c < chunks; c++) {
-        int t0 = c * chunk, t1 = t0 + chunk < G.num_ops ? t0 + chunk : G.num_ops;
+    for (long long i = 0; i < (long long)n; i++) body_scalar<Emit>(G, B, (size_t)i);
+    // same dependency order as the stream plan of p2e_hip.hip, with the MSM chain cut into `pieces` pieces whose
+    // phases B and C are interleaved with the following pieces of the chain
+    auto binv = [&](int lo, int hi) {
+        for (int t0 = lo; t0 < hi; t0 += chunk) {
+            int t1 = t0 + chunk < hi ? t0 + chunk : hi;
 #pragma omp parallel for
-        for (long long i = 0; i < (long long)n; i++) body_batch_inv(G, B, (size_t)i, t0, t1);
-    }
+            for (long long i = 0; i < (long long)n; i++) body_batch_inv(G, B, (size_t)i, t0, t1);
+        }
+    };
+    auto chain = [&](int lo, int hi) {
 #pragma omp parallel for
-    for (long long i = 0; i < (long long)n; i++)
-        for (int t = 0; t < G.num_ops; t++) body_expand(G, B, (size_t)i, t);
+        for (long long i = 0; i < (long long)n; i++) body_chain_range(G, B, (size_t)i, lo, hi);
+    };
+    auto expand = [&](int lo, int hi) {
+#pragma omp parallel for
+        for (long long i = 0; i < (long long)n; i++)
+            for (int t = lo; t < hi; t++) body_expand<Emit>(G, B, (size_t)i, t);
+    };
+    const int pieces = 3;
+    if (G.num_chains == 3) {
+        chain(G.chain_begin[1], G.chain_end[1]);
+        binv(G.chain_begin[1], G.chain_end[1]);
+        expand(G.chain_begin[1], G.chain_end[1]);
+    }
+    {
+        int lo = G.chain_begin[0], hi = G.chain_end[0];
+        int per = (hi - lo + pieces - 1) / pieces;
+        for (int a = lo; a < hi; a += per) {
+            int b = a + per < hi ? a + per : hi;
+            chain(a, b);
+            if (b == hi && G.num_chains == 3) {
+                chain(G.chain_begin[2], G.chain_end[2]);
+                b = G.chain_end[2];
+            }
+            binv(a, b);
+            expand(a, b);
+        }
+    }
     long bad = 0;
     for (size_t i = 0; i < n; i++) {
         err[i] = (uint8_t)err32[i];
