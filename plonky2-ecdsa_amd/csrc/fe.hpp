@@ -543,19 +543,43 @@ P2E_HD U256 fe_inv<ModN>(const U256& a) {
 // ------------------------------------------------------------------------------------------------
 // 29-bit limb split / pack (reference gadgets/biguint.rs:27-51 convert_base, :454-463 set_biguint_target)
 // ------------------------------------------------------------------------------------------------
-// limb k of an NW-word value
+// funnel shift right: low 32 bits of (hi:lo) >> sh, 0 < sh < 32
+P2E_HD u32 fsr(u32 lo, u32 hi, int sh) { return (lo >> sh) | (hi << (32 - sh)); }
+// limb k of an NW-word value.  Written with scalar operands only (no 64-bit pair built from two array
+// elements): hipcc otherwise keeps the word array in scratch memory to read the pairs as unaligned
+// 64-bit loads, and a scratch reload in the middle of a kernel waits (vmcnt is in-order) for every
+// column store issued before it.
 template <int NW>
 P2E_HD u32 limb29(const u32* w, int k) {
-    int bit = BITS * k;
-    int wi = bit >> 5, sh = bit & 31;
+    const int bit = BITS * k;
+    const int wi = bit >> 5, sh = bit & 31;
     if (wi >= NW) return 0;
-    u64 lo = w[wi];
-    u64 hi = (wi + 1 < NW) ? w[wi + 1] : 0u;
-    return (u32)(((lo | (hi << 32)) >> sh)) & MASK29;
+    if (sh == 0) return w[wi] & MASK29;
+    if (sh <= 3 || wi + 1 >= NW) return (w[wi] >> sh) & MASK29;
+    return fsr(w[wi], w[wi + 1], sh) & MASK29;
 }
 P2E_HD void split29(const U256& a, u32* l /*9*/) {
-    P2E_UNROLL
-    for (int k = 0; k < NL; k++) l[k] = limb29<8>(a.w, k);
+    l[0] = a.w[0] & MASK29;
+    l[1] = fsr(a.w[0], a.w[1], 29) & MASK29;
+    l[2] = fsr(a.w[1], a.w[2], 26) & MASK29;
+    l[3] = fsr(a.w[2], a.w[3], 23) & MASK29;
+    l[4] = fsr(a.w[3], a.w[4], 20) & MASK29;
+    l[5] = fsr(a.w[4], a.w[5], 17) & MASK29;
+    l[6] = fsr(a.w[5], a.w[6], 14) & MASK29;
+    l[7] = fsr(a.w[6], a.w[7], 11) & MASK29;
+    l[8] = a.w[7] >> 8;
+}
+// same for a 9-word value (the quotient of the witness multiplication, < 2^261)
+P2E_HD void split29_9(const u32* w /*9*/, u32* l /*9*/) {
+    l[0] = w[0] & MASK29;
+    l[1] = fsr(w[0], w[1], 29) & MASK29;
+    l[2] = fsr(w[1], w[2], 26) & MASK29;
+    l[3] = fsr(w[2], w[3], 23) & MASK29;
+    l[4] = fsr(w[3], w[4], 20) & MASK29;
+    l[5] = fsr(w[4], w[5], 17) & MASK29;
+    l[6] = fsr(w[5], w[6], 14) & MASK29;
+    l[7] = fsr(w[6], w[7], 11) & MASK29;
+    l[8] = fsr(w[7], w[8], 8) & MASK29;
 }
 // 9 limbs (each < 2^29) -> 9 words (261 bits)
 P2E_HD void pack29_wide(const u32* l /*9*/, u32* w /*9*/) {

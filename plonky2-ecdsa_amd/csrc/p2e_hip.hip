@@ -273,7 +273,7 @@ static std::vector<OpDesc> host_ops(int program) {
 }
 
 struct ScratchLayout {
-    size_t px, py, pz, pw, pref, ax, ay, dig4, dig2, dyn, err32, valid8, total;
+    size_t px, py, pz, pw, pref, ax, ay, dig4, dig2, dyn, src, err32, valid8, total;
 };
 static ScratchLayout scratch_layout(const Program& G, size_t n) {
     ScratchLayout L{};
@@ -293,6 +293,7 @@ static ScratchLayout scratch_layout(const Program& G, size_t n) {
     L.dig4 = take((size_t)FB_WINDOWS * n);
     L.dig2 = take((size_t)MSM_DIGITS * n);
     L.dyn = take((size_t)G.num_cadd * n * 2);
+    L.src = take((size_t)G.num_ops * 2 * n * 2);
     L.err32 = take(n * 4);
     L.valid8 = take(n);
     L.total = off;
@@ -699,6 +700,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     B.dig4 = (uint8_t*)(base + L.dig4);
     B.dig2 = (uint8_t*)(base + L.dig2);
     B.dyn = (uint16_t*)(base + L.dyn);
+    B.src = (uint16_t*)(base + L.src);
     B.cpts = c->d_cpts;
     B.fbtab = c->d_fbtab;
     B.ops = DP.d_ops;

@@ -24,6 +24,9 @@ P2E_HD constexpr u32 make_ref(u32 kind, u32 id) { return (kind << 24) | id; }
 P2E_HD constexpr u32 ref_kind(u32 r) { return r >> 24; }
 P2E_HD constexpr u32 ref_id(u32 r) { return r & 0xFFFFFFu; }
 constexpr uint16_t DYN_CONST_BIT = 0x8000;
+// encoding of src[]: bit 15 constant point, bit 14 fixed-base table entry (id = window * 16 + digit),
+// bit 13 (operand 2 of a conditional add only) the select bit "digit != 0"
+constexpr uint16_t SRC_FB_BIT = 0x4000, SRC_SEL_BIT = 0x2000, SRC_ID_MASK = 0x1FFF;
 
 struct OpDesc {
     uint8_t kind;       // OpKind
@@ -73,6 +76,7 @@ struct Buffers {
     uint8_t* dig4;   // [66][n]
     uint8_t* dig2;   // [73][n]   4*m_d + n_d
     uint16_t* dyn;   // [num_cadd][n]
+    uint16_t* src;   // [2 * num_ops][n]: resolved operand ids of every op (written by phase A for phase C)
     // constants
     const Aff* cpts;   // [NUM_CONST_PTS]
     const Aff* fbtab;  // [66][16]
@@ -221,7 +225,7 @@ P2E_HD uint16_t resolve_src(const Program& G, const Buffers& B, size_t i, u32 re
 P2E_HD Aff load_aff_src(const Buffers& B, size_t i, uint16_t src) {
     Aff a;
     if (src & DYN_CONST_BIT) {
-        a = B.cpts[src & 0x7FFF];
+        a = B.cpts[src & SRC_ID_MASK];
     } else {
         a.x = B.AX[(size_t)src * B.n + i];
         a.y = B.AY[(size_t)src * B.n + i];
@@ -255,19 +259,23 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t) {
     JacW res;
     uint16_t src1 = resolve_src(G, B, i, op.ref1);
     Jac p1 = load_jac_src(B, i, src1, (op.flags & F_Z1ONE) != 0);
+    B.src[(size_t)(2 * t) * B.n + i] = src1;
     if (op.kind == OP_DBL) {
         res = jac_dbl(p1);
     } else {
         Jac p2;
         u32 digit = 1;
+        uint16_t src2;
         if (ref_kind(op.ref2) == R_FBTAB) {
             Aff a = load_fbtab(B, i, ref_id(op.ref2), digit);
             p2 = jac_from_aff(a);
+            src2 = (uint16_t)(SRC_FB_BIT | (ref_id(op.ref2) * 16 + digit));
         } else {
             if (ref_kind(op.ref2) == R_MSMTAB) digit = B.dig2[(size_t)ref_id(op.ref2) * B.n + i];
-            uint16_t src2 = resolve_src(G, B, i, op.ref2);
+            src2 = resolve_src(G, B, i, op.ref2);
             p2 = load_jac_src(B, i, src2, (op.flags & F_Z2ONE) != 0);
         }
+        B.src[(size_t)(2 * t + 1) * B.n + i] = (uint16_t)(src2 | (digit != 0 ? SRC_SEL_BIT : 0));
         // the Z-one specialisations only skip multiplications by one: pick by the host-known flags
         if ((op.flags & F_Z1ONE) && (op.flags & F_Z2ONE))
             res = jac_add<true, true>(p1, p2);
@@ -362,22 +370,19 @@ P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t) {
     const OpDesc op = B.ops[t];
     uint8_t err = 0;
     E e = E::at(B.out, B.ld, i, op.col);
+    // operands were resolved by phase A: one level of index loads, then the points
+    const uint16_t s1 = B.src[(size_t)(2 * t) * B.n + i];
+    const uint16_t s2 = op.kind == OP_DBL ? (uint16_t)0 : B.src[(size_t)(2 * t + 1) * B.n + i];
     U256 vinv = B.PW[(size_t)t * B.n + i];
-    Aff p1 = load_aff_src(B, i, resolve_src(G, B, i, op.ref1));
+    Aff p1 = load_aff_src(B, i, s1);
     if (op.kind == OP_DBL) {
         (void)wit_curve_double(e, p1, vinv, err);
     } else {
-        Aff p2;
-        u32 digit = 1;
-        if (ref_kind(op.ref2) == R_FBTAB) {
-            p2 = load_fbtab(B, i, ref_id(op.ref2), digit);
-        } else {
-            if (ref_kind(op.ref2) == R_MSMTAB) digit = B.dig2[(size_t)ref_id(op.ref2) * B.n + i];
-            p2 = load_aff_src(B, i, resolve_src(G, B, i, op.ref2));
-        }
+        Aff p2 = (s2 & SRC_FB_BIT) ? B.fbtab[s2 & SRC_ID_MASK] : load_aff_src(B, i, (uint16_t)(s2 & (DYN_CONST_BIT | SRC_ID_MASK)));
+        const bool sel = (s2 & SRC_SEL_BIT) != 0;
         Aff s = wit_curve_add(e, p1, p2, vinv, err);
         if (op.kind == OP_CADD) {  // gadgets/curve.rs:225-243: sum always computed (Q7), then selected
-            bool b = digit != 0;
+            bool b = sel;
             (void)wit_add<ModP>(e, b ? s.x : u256_zero(), b ? u256_zero() : p1.x);
             (void)wit_add<ModP>(e, b ? s.y : u256_zero(), b ? u256_zero() : p1.y);
         }

@@ -85,8 +85,7 @@ P2E_HD uint8_t prim_mul(const u64* x, const u64* y, u64* r, u64* q, u64* cs, u64
     if (qw[8] >> 5) err |= ERR_QUOTIENT_RANGE;  // q does not fit the gate's 9 q wires
     u32 q29[NL], r29[NL];
     split29(rv, r29);
-    P2E_UNROLL
-    for (int k = 0; k < NL; k++) q29[k] = limb29<9>(qw, k);
+    split29_9(qw, q29);
     u64 tmp[51];
     ArrEmit e{tmp, 0};
     uint8_t e2 = 0;

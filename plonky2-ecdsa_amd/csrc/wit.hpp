@@ -209,8 +209,7 @@ P2E_HD void wit_inv_given(E& e, const U256& x_raw, const U256& inv, uint8_t& err
     reduce16<MOD, true>(prod, r, q);
     emit_u256(e, inv);
     u32 ql[NL];
-    P2E_UNROLL
-    for (int k = 0; k < NL; k++) ql[k] = limb29<9>(q, k);
+    split29_9(q, ql);
     emit_limbs(e, ql, NL);
 }
 // stand-alone form: one Fermat ladder per call
@@ -293,8 +292,7 @@ P2E_HD U256 wit_mul(E& e, const U256& x, const U256& y, uint8_t& err) {
     split29(x, x29);
     split29(y, y29);
     split29(r, r29);
-    P2E_UNROLL
-    for (int k = 0; k < NL; k++) q29[k] = limb29<9>(q, k);
+    split29_9(q, q29);
     emit_mul_rows<MOD>(e, x29, y29, q29, r29, err);
     return r;
 }

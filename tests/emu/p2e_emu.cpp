@@ -25,7 +25,7 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     std::vector<U256> PX((size_t)G.num_slots * n), PY((size_t)G.num_slots * n), PZ((size_t)G.num_slots * n),
         PW((size_t)G.num_ops * n), PREF((size_t)G.num_ops * n), AX((size_t)G.num_slots * n), AY((size_t)G.num_slots * n);
     std::vector<uint8_t> dig4((size_t)FB_WINDOWS * n), dig2((size_t)MSM_DIGITS * n), valid8(n);
-    std::vector<uint16_t> dyn((size_t)G.num_cadd * n);
+    std::vector<uint16_t> dyn((size_t)G.num_cadd * n), src((size_t)G.num_ops * 2 * n);
     std::vector<u32> err32(n);
     Buffers B{};
     B.msg = msg; B.r = r; B.s = s; B.pkx = pkx; B.pky = pky;
@@ -33,7 +33,7 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     B.err = err32.data(); B.valid = valid8.data();
     B.PX = PX.data(); B.PY = PY.data(); B.PZ = PZ.data(); B.PW = PW.data(); B.PREF = PREF.data();
     B.AX = AX.data(); B.AY = AY.data();
-    B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data();
+    B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data(); B.src = src.data();
     B.cpts = C.cpts; B.fbtab = C.fbtab.data(); B.ops = sb.ops.data();
 #pragma omp parallel for
     for (long long i = 0; i < (long long)n; i++) body_scalar<Emit>(G, B, (size_t)i);

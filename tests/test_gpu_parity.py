@@ -83,6 +83,26 @@ def test_verify_random_batch_ragged(gpu, ora):
     assert np.array_equal(np.asarray(got).view(np.uint64), want)
 
 
+@pytest.mark.parametrize("n,ld_pad", [(1000, 0), (1000, 1), (768, 6)])
+def test_verify_wide_and_tail_launches(ora, n, ld_pad):
+    """n = 1000: three full workgroups take the 16-byte paired-store kernels, the 232-signature tail the
+    8-byte ones; an odd column stride (ld_pad = 1) must fall back to 8-byte stores everywhere."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    sigs = p2e.synth_signatures(seed=123, n=n)
+    want, _, _ = ora.verify(*sigs)
+    ctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    ld = n + ld_pad
+    big = torch.zeros((p2e.VERIFY_COLS, ld), dtype=torch.int64, device="cuda")
+    cols, err, valid, bad = ctx.ecdsa_verify_witness_batch(*dev, cols=big[:, :n], ld=ld)
+    torch.cuda.synchronize()
+    assert bad == 0 and bool(valid.cpu().numpy().all())
+    host = big.cpu().numpy().view(np.uint64)
+    assert np.array_equal(host[:, :n], want)
+    assert not host[:, n:].any()
+
+
 def test_cfg3_glv_mul_1024(gpu, ora):
     """BASELINE config 3: 2^10 glv_mul witness fills."""
     import plonky2_ecdsa_amd as p2e
