@@ -55,9 +55,13 @@ def cpu_baseline(p2e, seed):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c
     cores = usable_cores(oracle_c.max_threads())
-    n = max(64, 100 * cores)                                  # ~25 ms per fill per thread -> 10-20 s
+    probe = p2e.synth_signatures(seed=seed, n=4 * cores)
+    oracle_c.verify_witness(*[a[:cores] for a in probe], nthreads=cores)   # warm-up (constant tables, threads)
+    t = time.time()
+    oracle_c.verify_witness(*probe, nthreads=cores)
+    rate = len(probe[0]) / max(time.time() - t, 1e-3)
+    n = int(min(max(64, rate * 12.0), 20000))                            # sized for ~12 s of CPU work
     sigs = p2e.synth_signatures(seed=seed, n=n)
-    oracle_c.verify_witness(*[a[:cores] for a in sigs], nthreads=cores)   # warm-up (constant tables, threads)
     t = time.time()
     cols, err, flags = oracle_c.verify_witness(*sigs, nthreads=cores)
     dt = time.time() - t
@@ -101,13 +105,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU.  P2E_DIST_BACKEND=gloo is for rehearsing the N>1 code path on a box with fewer
+    # GPUs than ranks (ranks then share devices); the driver's runs use the default, nccl (= RCCL over xGMI).
+    backend = os.environ.get("P2E_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(dev_index)
+    dev = f"cuda:{dev_index}"
+    local_rank = dev_index
 
     n = 1 << args.batch_log2
     total = n * world
@@ -152,7 +164,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -162,7 +174,7 @@ def main():
         k = min(args.allgather_cols, p2e.VERIFY_COLS)
         barrier()
         tg = time.perf_counter()
-        g = all_gather_columns(cols[:k], total)
+        g = all_gather_columns(cols[:k] if backend == "nccl" else cols[:k].cpu(), total)
         barrier()
         tg = time.perf_counter() - tg
         gather = {"cols": k, "bytes_per_rank_out": int(g.numel() * 8), "ms": round(tg * 1e3, 3),

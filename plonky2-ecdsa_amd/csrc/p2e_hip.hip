@@ -21,7 +21,7 @@ using namespace p2e;
 // kernels
 // ====================================================================================================
 constexpr int BS = 256;          // 4 waves per workgroup
-constexpr int BINV_TARGET = 64;  // ~curve ops per Montgomery batch (one Fermat ladder each)
+constexpr int BINV_TARGET_DEFAULT = 64;  // ~curve ops per Montgomery batch (one Fermat ladder each)
 
 // Signature owned by this lane.  WIDE kernels (full workgroups only) give lanes l and l+32 of a wave
 // adjacent signatures so that column pairs can be written with 16-byte stores (PairEmit); the narrow
@@ -235,7 +235,7 @@ struct p2e_ctx {
     double expand_cols[MAX_SEG] = {};
     float expand_ms_sum = 0.f;
     double expand_cols_sum = 0.0;
-    int msm_pieces = 6, fixed_pieces = 1;
+    int msm_pieces = 6, fixed_pieces = 1, binv_target = BINV_TARGET_DEFAULT;
     Aff* d_cpts = nullptr;
     Aff* d_fbtab = nullptr;
     DeviceProgram progs[2];
@@ -356,6 +356,10 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     if (const char* env = getenv("P2E_MSM_PIECES")) {
         int v = atoi(env);
         if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->msm_pieces = v;
+    }
+    if (const char* env = getenv("P2E_BINV_TARGET")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= 512) c->binv_target = v;
     }
     if (const char* env = getenv("P2E_FIXED_PIECES")) {
         int v = atoi(env);
@@ -773,7 +777,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     for (int q = 0; q < ns; q++) {
         const int k = order[q];
         const Seg& sg = segs[k];
-        unsigned nch = (unsigned)((sg.hi - sg.lo + BINV_TARGET - 1) / BINV_TARGET);
+        unsigned nch = (unsigned)((sg.hi - sg.lo + c->binv_target - 1) / c->binv_target);
         int ch = (sg.hi - sg.lo + (int)nch - 1) / (int)nch;
         // HIP multiplexes streams onto a few hardware queues (4 by default) and kernels of one queue run
         // in order: a dedicated inversion stream ended up sharing the caller's queue and serialised B

@@ -27,7 +27,7 @@ def per_kernel(path, counter):
         return acc
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] == counter:
-            acc[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+            acc[row["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]].append(float(row["Counter_Value"]))
     return acc
 
 
@@ -39,18 +39,22 @@ cal_w = per_kernel(os.path.join(src, "cal_write", "cal_counter_collection.csv"),
 out = {"source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py batch 2^16)",
        "units": "counters are KiB; bytes = value * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half "
                 "of a 16 B/lane streaming read)", "kernels": {}}
+# the PMC runs use bench.py --steps 2 --warmup 1 : 3 pipeline steps, so per-step sums = total / 3
+STEPS = 3
 for k in ("k_expand", "k_batch_inv", "k_chains", "k_scalar"):
     f = fetch.get(k, [])
     w = write.get(k, [])
     if not f and not w:
         continue
-    fb = max(f) * 1024 if f else None       # per launch (largest launch: k_chains has a tiny second stage)
-    wb = max(w) * 1024 if w else None
-    out["kernels"][k] = {"launches_seen": len(f), "FETCH_SIZE_bytes_raw": fb, "WRITE_SIZE_bytes": wb,
-                         "fetch_bytes_corrected_x2": fb * 2 if fb else None,
-                         "hbm_bytes_per_launch": (fb * 2 if fb else 0) + (wb or 0)}
+    fb = sum(f) * 1024 / STEPS if f else None
+    wb = sum(w) * 1024 / STEPS if w else None
+    out["kernels"][k] = {"launches_per_step": len(f) // STEPS, "FETCH_SIZE_bytes_raw_per_step": fb,
+                         "WRITE_SIZE_bytes_per_step": wb, "fetch_bytes_corrected_x2_per_step": fb * 2 if fb else None,
+                         "hbm_bytes_per_step": (fb * 2 if fb else 0) + (wb or 0)}
 if "k_expand" in out["kernels"]:
-    out["hbm_bytes_per_launch"] = out["kernels"]["k_expand"]["hbm_bytes_per_launch"]
+    ke = out["kernels"]["k_expand"]
+    out["hbm_bytes_per_launch_avg"] = ke["hbm_bytes_per_step"] / max(1, ke["launches_per_step"])
+out["hbm_bytes_per_step_all_kernels"] = sum(v["hbm_bytes_per_step"] for v in out["kernels"].values())
 cal = []
 fl, wl = cal_f.get("k_split", []), cal_w.get("k_split", [])
 per = max(1, len(fl) // 3)                      # dispatches per size (warm-up + REPS), sizes in launch order
