@@ -109,17 +109,6 @@ P2E_HD Jac jac_from_aff(const Aff& a) {
     j.Z = u256_small(1);
     return j;
 }
-P2E_HD Jac jac_select(bool b, const Jac& t, const Jac& f) {
-    Jac o;
-    P2E_UNROLL
-    for (int i = 0; i < 8; i++) {
-        o.X.w[i] = b ? t.X.w[i] : f.X.w[i];
-        o.Y.w[i] = b ? t.Y.w[i] : f.Y.w[i];
-        o.Z.w[i] = b ? t.Z.w[i] : f.Z.w[i];
-    }
-    return o;
-}
-
 // affine helpers for the HOST only (constant tables at context creation, synthetic inputs)
 P2E_HD Aff aff_add(const Aff& p, const Aff& q) {
     U256 l = fp_mul(fp_sub(q.y, p.y), fe_inv_p(fp_sub(q.x, p.x)));

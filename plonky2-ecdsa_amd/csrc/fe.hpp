@@ -482,10 +482,6 @@ template <class MOD>
 P2E_HD U256 fe_neg(const U256& a) {
     return fe_sub<MOD>(u256_zero(), a);
 }
-template <class MOD>
-P2E_HD U256 fe_dbl(const U256& a) {
-    return fe_add<MOD>(a, a);
-}
 // to_canonical_biguint of the reference's field types: ONE conditional subtraction
 template <class MOD>
 P2E_HD U256 fe_canon(const U256& a) {
@@ -545,19 +541,10 @@ P2E_HD U256 fe_inv<ModN>(const U256& a) {
 // ------------------------------------------------------------------------------------------------
 // funnel shift right: low 32 bits of (hi:lo) >> sh, 0 < sh < 32
 P2E_HD u32 fsr(u32 lo, u32 hi, int sh) { return (lo >> sh) | (hi << (32 - sh)); }
-// limb k of an NW-word value.  Written with scalar operands only (no 64-bit pair built from two array
-// elements): hipcc otherwise keeps the word array in scratch memory to read the pairs as unaligned
-// 64-bit loads, and a scratch reload in the middle of a kernel waits (vmcnt is in-order) for every
-// column store issued before it.
-template <int NW>
-P2E_HD u32 limb29(const u32* w, int k) {
-    const int bit = BITS * k;
-    const int wi = bit >> 5, sh = bit & 31;
-    if (wi >= NW) return 0;
-    if (sh == 0) return w[wi] & MASK29;
-    if (sh <= 3 || wi + 1 >= NW) return (w[wi] >> sh) & MASK29;
-    return fsr(w[wi], w[wi + 1], sh) & MASK29;
-}
+// 29-bit limbs of an 8-word value.  Written with scalar operands only (no 64-bit pair built from two
+// array elements): hipcc otherwise keeps the word array in scratch memory to read the pairs as unaligned
+// 64-bit loads, and a scratch reload in the middle of a kernel waits (vmcnt is in-order) for every column
+// store issued before it.
 P2E_HD void split29(const U256& a, u32* l /*9*/) {
     l[0] = a.w[0] & MASK29;
     l[1] = fsr(a.w[0], a.w[1], 29) & MASK29;

@@ -97,12 +97,6 @@ P2E_HD U256 load_packed(const uint8_t* base, size_t i) {
     for (int k = 0; k < 8; k++) r.w[k] = p[k];
     return r;
 }
-P2E_HD U256 u256_from_words(const u32* w) {
-    U256 r;
-    P2E_UNROLL
-    for (int k = 0; k < 8; k++) r.w[k] = w[k];
-    return r;
-}
 // digit t (width WB) of a value = bits [WB*t, WB*t+WB): identical to the reference's per-limb LE bit
 // split + regroup (gadgets/split_nonnative.rs:25-72) because limbs are 29 contiguous bits each
 template <int WB>
