@@ -119,6 +119,13 @@ long p2e_ecdsa_verify_witness_batch(p2e_ctx *ctx, const uint8_t *msg32, const ui
 long p2e_glv_mul_witness_batch(p2e_ctx *ctx, const uint8_t *px32, const uint8_t *py32, const uint8_t *k32,
                                uint64_t *cols, size_t n, size_t ld, uint8_t *err, uint8_t *valid);
 
+/* ---- layout helper --------------------------------------------------------------------------------- */
+/* cols[ncols][ld] (column-major over the batch) -> rows[n][row_ld], one contiguous witness per signature:
+ * what a per-signature PartialWitness fill (pw.set_biguint_target ... gadgets/biguint.rs:454-463 per target,
+ * INTEGRATION.md section 3) wants to read.  row_ld >= ncols. */
+long p2e_columns_to_rows(p2e_ctx *ctx, const uint64_t *cols, size_t ld, size_t n, size_t ncols, uint64_t *rows,
+                         size_t row_ld);
+
 /* ---- schedule description (column -> generator map, host only, no GPU needed) ---------------------- */
 typedef struct p2e_gen_desc {
     int32_t kind;  /* 0 add, 1 sub, 2 add_many, 3 mul(+checksum), 4 inv, 5 glv_decomposition */

@@ -37,7 +37,8 @@ EXPORTS = (
     "p2e_ctx_create", "p2e_ctx_destroy", "p2e_sync", "p2e_last_error", "p2e_scratch_bytes", "p2e_last_phase_ms",
     "p2e_mul_witness_batch", "p2e_checksum_witness_batch", "p2e_add_witness_batch", "p2e_sub_witness_batch",
     "p2e_add_many_witness_batch", "p2e_inv_witness_batch", "p2e_glv_decompose_batch", "p2e_limb_split",
-    "p2e_limb_pack", "p2e_ecdsa_verify_witness_batch", "p2e_glv_mul_witness_batch", "p2e_schedule_describe",
+    "p2e_limb_pack", "p2e_ecdsa_verify_witness_batch", "p2e_glv_mul_witness_batch", "p2e_columns_to_rows",
+    "p2e_schedule_describe",
     "p2e_schedule_num_cols", "p2e_synth_signatures",
 )
 
@@ -75,6 +76,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise P2EError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+        # torch ships its own libamdhip64 / libhsa-runtime64.  Import it FIRST so that libp2e_hip.so resolves
+        # its libamdhip64.so.7 dependency to the runtime torch already loaded: device pointers and streams
+        # are only meaningful inside one HIP runtime, and a second HSA runtime in the process finds no GPU
+        # ("No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(_lib, name)  # AttributeError if a declared symbol is not exported
@@ -82,7 +91,7 @@ def lib():
         _lib.p2e_scratch_bytes.restype = C.c_size_t
         _lib.p2e_scratch_bytes.argtypes = [C.c_int, C.c_size_t]
         for name in EXPORTS:
-            if name.endswith("_batch") or name in ("p2e_limb_split", "p2e_limb_pack", "p2e_schedule_describe",
+            if name.endswith("_batch") or name in ("p2e_limb_split", "p2e_limb_pack", "p2e_columns_to_rows", "p2e_schedule_describe",
                                                    "p2e_schedule_num_cols"):
                 getattr(_lib, name).restype = C.c_long
     return _lib
@@ -252,6 +261,21 @@ class Context:
         err = self._vec(n, np.uint8)
         bad = self._check(self._L.p2e_limb_pack(self._h, _ptr(limbs), _ptr(packed), C.c_size_t(n), C.c_size_t(n), _ptr(err)))
         return packed, err, bad
+
+    def columns_to_rows(self, cols, n=None, ld=None, rows=None):
+        """(ncols, ld) column-major matrix -> (n, ncols) matrix with one contiguous witness per signature."""
+        ncols = self._shape(cols)[0]
+        ld = ld if ld is not None else self._shape(cols)[1]
+        n = n if n is not None else self._shape(cols)[1]
+        if rows is None:
+            if self.host_pointers:
+                rows = np.zeros((n, ncols), dtype=np.uint64)
+            else:
+                import torch
+                rows = torch.empty((n, ncols), dtype=torch.int64, device=f"cuda:{self.device}")
+        self._check(self._L.p2e_columns_to_rows(self._h, _ptr(cols), C.c_size_t(ld), C.c_size_t(n), C.c_size_t(ncols),
+                                                _ptr(rows), C.c_size_t(self._shape(rows)[1])))
+        return rows
 
     # ---- fused schedules -----------------------------------------------------------------------------
     def ecdsa_verify_witness_batch(self, msg, r, s, pkx, pky, cols=None, err=None, valid=None, ld=None):

@@ -196,6 +196,27 @@ __global__ __launch_bounds__(BS) void k_pack(const u64* limbs, uint8_t* packed, 
     count_err(e, counter);
 }
 
+// Column-major witness matrix -> one contiguous row per signature (what a per-signature PartialWitness
+// fill wants to read): 64 x 64 u64 tiles through LDS, both global sides coalesced 512-byte runs.
+// Rows of the tile are padded to 65 elements so the transposed read walks distinct banks.
+__global__ __launch_bounds__(BS) void k_transpose(const u64* __restrict__ cols, size_t ld, size_t n, size_t ncols,
+                                                  u64* __restrict__ rows, size_t row_ld) {
+    __shared__ u64 tile[64][65];
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t s0 = (size_t)blockIdx.x * 64, c0 = (size_t)blockIdx.y * 64;
+#pragma unroll 4
+    for (unsigned r = w; r < 64; r += 4) {   // column c0 + r, signatures s0 .. s0 + 63
+        size_t c = c0 + r, sg = s0 + lane;
+        if (c < ncols && sg < n) tile[r][lane] = cols[c * ld + sg];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (unsigned r = w; r < 64; r += 4) {   // signature s0 + r, columns c0 .. c0 + 63
+        size_t sg = s0 + r, c = c0 + lane;
+        if (sg < n && c < ncols) rows[sg * row_ld + c] = tile[lane][r];
+    }
+}
+
 // ====================================================================================================
 // context
 // ====================================================================================================
@@ -827,6 +848,20 @@ extern "C" long p2e_glv_mul_witness_batch(p2e_ctx* c, const uint8_t* px32, const
     if (bad_common(c, n, ld) || !px32 || !py32 || !k32 || !cols || !err) return P2E_E_INVALID;
     if (n == 0) return 0;
     return run_program(c, 1, k32, k32, k32, px32, py32, cols, n, ld, err, valid);
+}
+
+extern "C" long p2e_columns_to_rows(p2e_ctx* c, const uint64_t* cols, size_t ld, size_t n, size_t ncols,
+                                    uint64_t* rows, size_t row_ld) {
+    if (bad_common(c, n, ld) || !cols || !rows || row_ld < ncols) return P2E_E_INVALID;
+    if (n == 0 || ncols == 0) return 0;
+    Staged S(c);
+    cols = S.in(cols, ncols * ld * 8);
+    rows = S.out(rows, n * row_ld * 8);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    dim3 grid((unsigned)((n + 63) / 64), (unsigned)((ncols + 63) / 64));
+    hipLaunchKernelGGL(k_transpose, grid, dim3(BS), 0, c->stream, cols, ld, n, ncols, rows, row_ld);
+    return S.done(finish_call(c));
 }
 
 // ====================================================================================================

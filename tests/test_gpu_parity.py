@@ -164,6 +164,24 @@ def test_device_pointers_ld_and_async():
     assert bool(valid.cpu().numpy().all()) and not err.cpu().numpy().any()
 
 
+def test_columns_to_rows(gpu):
+    """Layout helper: column-major witness -> one contiguous row per signature (ragged sizes, padded strides)."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    rng = np.random.default_rng(9)
+    for n, ncols, ld in ((1, 1, 1), (70, 131, 70), (301, 517, 320), (64, 64, 64)):
+        cols = rng.integers(0, 2**63, size=(ncols, ld), dtype=np.int64).astype(np.uint64)
+        rows = gpu.ctx.columns_to_rows(cols, n=n, ld=ld)
+        assert np.array_equal(np.asarray(rows), cols[:, :n].T)
+    # device pointers, on the real witness
+    sigs = p2e.synth_signatures(seed=55, n=130)
+    ctx = p2e.Context(device=0)
+    cols, err, valid, bad = ctx.ecdsa_verify_witness_batch(*[torch.from_numpy(a).cuda() for a in sigs])
+    rows = ctx.columns_to_rows(cols)
+    torch.cuda.synchronize()
+    assert torch.equal(rows, cols.t())
+
+
 def test_api_misuse_returns_status_not_crash():
     import plonky2_ecdsa_amd as p2e
     ctx = p2e.Context(device=0, host_pointers=True)

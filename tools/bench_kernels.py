@@ -29,7 +29,7 @@ def timed(fn):
     return s.elapsed_time(e) / reps
 
 
-which = sys.argv[1:] or ["split", "mul", "pack"]
+which = sys.argv[1:] or ["split", "mul", "transpose"]
 if "split" in which:
     for lg in (20, 24, 26):
         n = 1 << lg
@@ -54,3 +54,11 @@ if "mul" in which:
                               "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / PEAK, 4),
                               "note": "includes output allocation by the python wrapper"}), flush=True)
         del x, y
+if "transpose" in which:
+    n = 1 << 14
+    cols = torch.randint(0, 1 << 62, (p2e.VERIFY_COLS, n + 16), dtype=torch.int64, device="cuda")
+    rows = torch.empty((n, p2e.VERIFY_COLS), dtype=torch.int64, device="cuda")
+    ms = timed(lambda: ctx.columns_to_rows(cols, n=n, ld=n + 16, rows=rows))
+    b = 2 * 8 * n * p2e.VERIFY_COLS
+    print(json.dumps({"kernel": "k_transpose", "n": n, "ncols": p2e.VERIFY_COLS, "ms": round(ms, 4), "alg_bytes": b,
+                      "GBps": round(b / ms / 1e6, 1), "frac_hbm_peak": round(b / ms / 1e6 / PEAK, 4)}), flush=True)
