@@ -65,6 +65,38 @@ def kat_mul(field):
     cases = [(0, 0), (1, 1), (1, m - 1), (m - 1, m - 1), (2**256 - 1, 2**256 - 1), (m, m), (m + 1, 2),
              (2**261 - 1, 1), (2**261 - 1, 2**261 - 1), (2**260, 2**257), (0, 2**256 - 1)]
     cases += [(rng.below(m), rng.below(m)) for _ in range(16)]
+    # Rare branches of a fold-style reduction (second/third carry, final "r >= m" correction) fire only when
+    # x*y mod m is tiny -- probability ~2^-125 on random operands: force them with y = r * x^-1 for small r,
+    # canonical and non-canonical (y + m < 2^256) operands.  (p: x = 2^256 - 1 case constructed analytically.)
+    for bits in (0, 1, 8, 32, 33, 64, 100, 128, 129, 130, 133):
+        for rep in range(4):
+            x = rng.below(m)
+            r = rng.next() | (rng.next() << 64) | (rng.next() << 128)
+            r &= (1 << bits) - 1
+            y = r * pow(x, -1, m) % m
+            if rep & 1 and y + m < 2**256:
+                y += m
+            cases.append((x, y))
+    if field == 0:
+        cases.append((2**256 - 1, 0xfffffc2c000e983fc85b8cd422f7173ab1f7703980a424c58e33ced0da7b7ff4))
+    else:
+        # third carry of the n-reduction (hi counts 8,5,1,1): search the small-remainder family until it fires
+        c = 2**256 - m
+        for _ in range(200000):
+            x = rng.below(m)
+            r = (rng.next() | (rng.next() << 64) | (rng.next() << 128)) & ((1 << 133) - 1)
+            y = r * pow(x, -1, m) % m
+            hi, lo = (x * y) >> 256, (x * y) & (2**256 - 1)
+            path = []
+            for _ in range(3):
+                t = lo + hi * c
+                hi, lo = t >> 256, t & (2**256 - 1)
+                path.append(hi)
+            if path[1] and path[2]:
+                cases.append((x, y))
+                break
+        else:
+            raise AssertionError("no third-carry case found")
     out = []
     for x, y in cases:
         def f():
@@ -149,6 +181,13 @@ def kat_checksum():
     return out
 
 
+def write_gz(path, text):
+    """deterministic gzip (no timestamp) so regenerating the goldens does not dirty the tree"""
+    with open(path, "wb") as raw:
+        with gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as f:
+            f.write(text.encode())
+
+
 def main():
     kats = {"add_sub": kat_add_sub(0) + kat_add_sub(1), "mul": kat_mul(0) + kat_mul(1),
             "inv": kat_inv(0) + kat_inv(1), "add_many": kat_add_many(0) + kat_add_many(1), "glv": kat_glv(),
@@ -192,8 +231,7 @@ def main():
                         inputs=np.frombuffer(b"".join(v.to_bytes(32, "little") for s in sigs for v in s),
                                              dtype=np.uint8).reshape(len(sigs), 5, 32),
                         valid=np.array(oks, dtype=np.uint8))
-    with gzip.open(os.path.join(OUT, "schedule_verify.json.gz"), "wt") as f:
-        json.dump([list(o) for o in ops], f, separators=(",", ":"))
+    write_gz(os.path.join(OUT, "schedule_verify.json.gz"), json.dumps([list(o) for o in ops], separators=(",", ":")))
 
     # glv_mul alone (BASELINE config 3)
     g_in = [(R.synth_signature_at(3, i)[3], R.synth_signature_at(3, i)[4], R.SplitMix64(33 + i).below(R.N))
@@ -207,8 +245,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "glv_mul_golden.npz"), cols=np.array(gcols, dtype=np.uint64).T.copy(),
                         inputs=np.frombuffer(b"".join(v.to_bytes(32, "little") for s in g_in for v in s),
                                              dtype=np.uint8).reshape(len(g_in), 3, 32))
-    with gzip.open(os.path.join(OUT, "schedule_glv_mul.json.gz"), "wt") as f:
-        json.dump([list(o) for o in gops], f, separators=(",", ":"))
+    write_gz(os.path.join(OUT, "schedule_glv_mul.json.gz"), json.dumps([list(o) for o in gops], separators=(",", ":")))
     print("wrote", sorted(os.listdir(OUT)))
 
 

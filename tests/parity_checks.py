@@ -136,3 +136,43 @@ def golden_schedule(name):
 
 
 ALL_PRIM_CHECKS = (check_add_sub, check_mul, check_inv, check_add_many, check_glv, check_checksum, check_split_pack)
+
+
+def structured_values(seed, count, bound_bits=256):
+    """Operands made of words with long runs of ones / zeros / alternating bits: the inputs on which
+    carry chains and fold-style reductions actually take their rare paths."""
+    rng = np.random.default_rng(seed)
+    words = np.array([0, 1, 2, 3, 0xFFFFFFFF, 0xFFFFFFFE, 0x80000000, 0x7FFFFFFF, 0x55555555, 0xAAAAAAAA,
+                      0xFFFFFC2F, 0xD0364141], dtype=np.uint64)
+    pick = rng.integers(0, len(words), size=(count, 8))
+    rnd = rng.integers(0, 1 << 32, size=(count, 8), dtype=np.uint64)
+    use_rnd = rng.random((count, 8)) < 0.2
+    w = np.where(use_rnd, rnd, words[pick])
+    vals = []
+    for row in w:
+        v = 0
+        for k in range(8):
+            v |= int(row[k]) << (32 * k)
+        vals.append(v & ((1 << bound_bits) - 1))
+    return vals
+
+
+def check_structured_mul_add_sub(be, ora, count=4000):
+    import oracle_c
+    for field in (0, 1):
+        x = oracle_c.limbs_cols(structured_values(10 + field, count))
+        y = oracle_c.limbs_cols(structured_values(20 + field, count))
+        for g, w in zip(be.mul(field, x, y), ora.mul(field, x, y)):
+            assert np.array_equal(np.asarray(g), w), f"mul field {field}"
+        for name in ("add", "sub"):
+            for g, w in zip(getattr(be, name)(field, x, y), getattr(ora, name)(field, x, y)):
+                assert np.array_equal(np.asarray(g), w), f"{name} field {field}"
+        k = x[:, : max(64, count // 16)]
+        got, want = be.inv(field, k), ora.inv(field, k)
+        assert np.array_equal(np.asarray(got[2]) != 0, want[2] != 0)
+        ok = want[2] == 0
+        for g, w in zip(got[:2], want[:2]):
+            assert np.array_equal(np.asarray(g)[:, ok], w[:, ok]), f"inv field {field}"
+    kk = oracle_c.limbs_cols(structured_values(30, count))
+    for g, w in zip(be.glv(kk), ora.glv(kk)):
+        assert np.array_equal(np.asarray(g), w), "glv"

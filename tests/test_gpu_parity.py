@@ -73,6 +73,11 @@ def test_inv_add_sub_random(gpu, ora, field):
         assert np.array_equal(np.asarray(g), w)
 
 
+def test_structured_operands(gpu, ora):
+    """Same structured-operand sweep as the CPU emulation, on the real kernels (asm multiply / squaring)."""
+    pc.check_structured_mul_add_sub(gpu, ora, count=20000)
+
+
 def test_verify_random_batch_ragged(gpu, ora):
     """n = 301: not a multiple of the wavefront / workgroup size."""
     import plonky2_ecdsa_amd as p2e

@@ -117,3 +117,31 @@ def test_inverse_of_zero_is_flagged_not_fatal():
     assert werr[1] & R.ERR_INVERSE_OF_ZERO and err[1] & R.ERR_INVERSE_OF_ZERO
     assert not err[0] and not err[2] and valid[0] and valid[2] and not valid[1]
     assert np.array_equal(got[:, [0, 2]], want[:, [0, 2]])
+
+
+def test_kernel_bodies_structured_operands():
+    """Carry chains / fold reductions on operands with long runs of ones and zeros (incl. values >= m)."""
+    pc.check_structured_mul_add_sub(EmuBackend(), OracleBackend(), count=3000)
+
+
+def test_rare_reduction_branches_are_in_the_goldens():
+    """The KATs must contain multiplications whose product is congruent to something tiny: only those take
+    the second-carry / final-correction paths of the fold reduction (csrc/fe.hpp reduce_p16, reduce_wide)."""
+    hits = {0: set(), 1: set()}
+    for k in pc.KATS["mul"]:
+        if k["err"]:
+            continue
+        m = R.MODULI[k["field"]]
+        x, y = R.value_of(k["x"]), R.value_of(k["y"])
+        if x >> 256 or y >> 256:
+            continue
+        c = 2**256 - m
+        hi, lo = (x * y) >> 256, (x * y) & (2**256 - 1)
+        path = []
+        for _ in range(4):
+            t = lo + hi * c
+            hi, lo = t >> 256, t & (2**256 - 1)
+            path.append(min(hi, 1))
+        hits[k["field"]].add((tuple(path[1:]), lo >= m))
+    assert ((1, 0, 0), False) in hits[0] and any(h[1] for h in hits[0])          # p: second carry, final r >= p
+    assert any(h[0][:2] == (1, 1) for h in hits[1]) and any(h[1] for h in hits[1])  # n: third carry, final r >= n
