@@ -29,6 +29,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP multiplexes streams onto this many hardware queues (default 4); the pipeline uses three streams per
+# context and kernels that share a queue run in order.  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 BYTES_PER_FILL = 661080          # 160 B packed inputs + 82 615 * 8 B outputs
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
@@ -94,6 +97,10 @@ def main():
     ap.add_argument("--allgather-cols", type=int, default=0,
                     help="N>1 only: after the timed region, all-gather this many columns over RCCL and report GB/s")
     ap.add_argument("--ld-pad", type=int, default=16, help="column stride = batch + this many elements")
+    ap.add_argument("--pipeline-depth", type=int, default=1,
+                    help="batches in flight per GPU: D > 1 issues step i on context/stream/output buffer i % D "
+                         "(asynchronous C ABI), so the scalar phase and first chain pieces of the next batch "
+                         "run under the expansion of the current one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,24 +133,41 @@ def main():
     from plonky2_ecdsa_amd.dist import shard_bounds
     start, end = shard_bounds(total, rank, world)
     sigs = p2e.synth_signatures(seed=4, n=end - start, first=start)       # seed 0x4: SURVEY.md 8(d) cfg-4
-    ctx = p2e.Context(device=local_rank)                                   # runs on torch's current stream
+    depth = max(1, args.pipeline_depth)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(depth - 1)]
+    ctxs = [p2e.Context(device=local_rank, stream=st.cuda_stream, asynchronous=depth > 1) for st in streams]
+    ctx = ctxs[0]
     inputs = [torch.from_numpy(a).to(dev) for a in sigs]
     # column stride: n + 16 elements.  A power-of-two stride (2^16 * 8 B = 512 KiB) makes consecutive columns
     # camp on the same HBM channels (measured -9 % on k_expand); ld is part of the C ABI (ld >= n).
     ld = n + args.ld_pad
-    cols_buf = torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device=dev)
-    cols = cols_buf[:, :n]
-    err = torch.empty(n, dtype=torch.uint8, device=dev)
-    valid = torch.empty(n, dtype=torch.uint8, device=dev)
+    cols_bufs = [torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device=dev) for _ in range(depth)]
+    cols = cols_bufs[0][:, :n]
+    errs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(depth)]
+    valids = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(depth)]
+    err, valid = errs[0], valids[0]
+    issued = [0]
 
     def step():
-        return ctx.ecdsa_verify_witness_batch(*inputs, cols=cols, err=err, valid=valid, ld=ld)[3]
+        k = issued[0] % depth
+        issued[0] += 1
+        if depth > 1 and issued[0] > depth:
+            ctxs[k].sync()                     # the batch issued `depth` steps ago on this context is done
+        return ctxs[k].ecdsa_verify_witness_batch(*inputs, cols=cols_bufs[k][:, :n], err=errs[k], valid=valids[k], ld=ld)[3]
+
+    def drain():
+        bad = 0
+        for c in ctxs:
+            bad += c.sync() if depth > 1 else 0
+        return bad
 
     for _ in range(args.warmup):
         bad = step()
+    bad = (drain() if depth > 1 else bad) if args.warmup else 0
     torch.cuda.synchronize()
     if args.warmup:
-        assert bad == 0 and int(valid.sum()) == n, "synthetic signatures must all verify"
+        assert bad == 0 and all(int(v.sum()) == n for v in valids[:min(depth, args.warmup)]), "synthetic signatures must all verify"
+    issued[0] = 0
 
     def barrier():
         if world > 1:
@@ -156,13 +180,24 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        if depth > 1:
+            continue
         ph = ctx.last_phase_ms()
         expand_ms.append(ph["expand"])
         expand_cols, expand_launches = ph["expand_cols"], int(ph["expand_launches"])
         for k in ("scalar", "expand", "total"):
             phase_acc[k] = phase_acc.get(k, 0.0) + ph[k]
+    if depth > 1:
+        drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    if depth > 1:                              # per-launch timings of the last batch of every context
+        for c in ctxs:
+            ph = c.last_phase_ms()
+            expand_ms.append(ph["expand"])
+            expand_cols, expand_launches = ph["expand_cols"], int(ph["expand_launches"])
+            for k in ("scalar", "expand", "total"):
+                phase_acc[k] = phase_acc.get(k, 0.0) + ph[k] * args.steps / depth
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,6 +233,7 @@ def main():
                                    "one GPU; random valid signatures, seed 4), all 82615 hot-path generator columns, "
                                    "column-major u64 in HBM",
                        "batch_per_gpu": n, "global_batch": total, "cols_per_fill": p2e.VERIFY_COLS, "ld": ld,
+                       "pipeline_depth": depth,
                        "parallelism": f"shard{world}" if world > 1 else "single"},
             "whole_fill": {"algorithmic_bytes_per_fill": BYTES_PER_FILL,
                            "GBps_per_gpu": round(value * BYTES_PER_FILL / world / 1e9, 1),
