@@ -308,7 +308,7 @@ P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0,
         B.PREF[o] = acc;
         acc = fp_mul(acc, z);
     }
-    U256 inv = fe_inv_p(acc);
+    U256 inv = fe_inv<ModP>(acc);
     for (int t = t1 - 1; t >= t0; t--) {
         size_t o = (size_t)t * B.n + i;
         U256 z = B.PZ[o];
@@ -377,8 +377,9 @@ P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t) {
         Aff s = wit_curve_add(e, p1, p2, vinv, err);
         if (op.kind == OP_CADD) {  // gadgets/curve.rs:225-243: sum always computed (Q7), then selected
             bool b = sel;
-            (void)wit_add<ModP>(e, b ? s.x : u256_zero(), b ? u256_zero() : p1.x);
-            (void)wit_add<ModP>(e, b ? s.y : u256_zero(), b ? u256_zero() : p1.y);
+            const U256 z = u256_zero();
+            (void)wit_add<ModP>(e, u256_select(b, s.x, z), u256_select(b, z, p1.x));
+            (void)wit_add<ModP>(e, u256_select(b, s.y, z), u256_select(b, z, p1.y));
         }
         if (op.flags & F_CHECK_R) {  // gadgets/ecdsa.rs:48-52 connect_nonnative(r, point.x)
             U256 r = load_packed(B.r, i);

@@ -301,8 +301,9 @@ P2E_HD U256 wit_mul(E& e, const U256& x, const U256& y, uint8_t& err) {
 template <class MOD, class E>
 P2E_HD U256 wit_cond_neg(E& e, const U256& x, u32 b) {
     U256 neg = wit_sub<MOD>(e, u256_zero(), x);
-    U256 t = b ? neg : u256_zero();
-    U256 f = b ? u256_zero() : x;
+    const U256 z = u256_zero();
+    U256 t = u256_select(b != 0, neg, z);
+    U256 f = u256_select(b != 0, z, x);
     return wit_add<MOD>(e, t, f);
 }
 

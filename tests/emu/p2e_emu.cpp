@@ -85,6 +85,48 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
 }
 
 extern "C" {
+// raw access to the binary-GCD inversion (csrc/fe.hpp) for the stress test: ok[i] = round bound held
+long emu_bingcd(int field, const uint8_t* x32, uint8_t* inv32, uint8_t* ok, size_t n) {
+    long fails = 0;
+#pragma omp parallel for reduction(+ : fails)
+    for (long long i = 0; i < (long long)n; i++) {
+        U256 x, r;
+        std::memcpy(x.w, x32 + 32 * i, 32);
+        bool good = field ? fe_inv_bingcd<ModN>(x, r) : fe_inv_bingcd<ModP>(x, r);
+        std::memcpy(inv32 + 32 * i, r.w, 32);
+        ok[i] = good;
+        fails += !good;
+    }
+    return fails;
+}
+// self-checking stress loop: x from splitmix64 with assorted bit lengths / word patterns, x * inv(x) == 1
+long emu_bingcd_selfcheck(int field, unsigned long long seed, size_t n) {
+    long fails = 0;
+#pragma omp parallel for reduction(+ : fails)
+    for (long long i = 0; i < (long long)n; i++) {
+        host::SplitMix64 rng{seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1))};
+        U256 x;
+        unsigned long long sel = rng.next();
+        for (int k = 0; k < 4; k++) {
+            unsigned long long w = rng.next();
+            unsigned pat = (unsigned)(sel >> (8 * k)) & 7;
+            if (pat == 0) w = 0;
+            if (pat == 1) w = ~0ull;
+            if (pat == 2) w &= 0xFFFFFFFFull;
+            x.w[2 * k] = (u32)w;
+            x.w[2 * k + 1] = (u32)(w >> 32);
+        }
+        int bits = 1 + (int)((sel >> 40) % 256);
+        for (int b = bits; b < 256; b++) x.w[b >> 5] &= ~(1u << (b & 31));
+        x = field ? fe_canon<ModN>(x) : fe_canon<ModP>(x);
+        if (u256_is_zero(x)) continue;
+        U256 r;
+        bool ok = field ? fe_inv_bingcd<ModN>(x, r) : fe_inv_bingcd<ModP>(x, r);
+        U256 one = field ? fe_mul<ModN>(x, r) : fe_mul<ModP>(x, r);
+        if (!ok || !u256_eq(one, u256_small(1))) fails++;
+    }
+    return fails;
+}
 long emu_verify(const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx, const uint8_t* pky,
                 uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid, int chunk) {
     return run(0, msg, r, s, pkx, pky, cols, n, ld, err, valid, chunk);

@@ -1,0 +1,36 @@
+"""A/B two builds of libp2e_hip.so in ONE process, interleaved rounds (cdna guide rule 24)."""
+import os, sys, time, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import numpy as np, torch
+import plonky2_ecdsa_amd as p2e
+libs = sys.argv[1:]
+n = 1 << 16
+sigs = p2e.synth_signatures(seed=4, n=n)
+dev = [torch.from_numpy(a).cuda() for a in sigs]
+ld = n + 16
+big = torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device="cuda")
+err = torch.empty(n, dtype=torch.uint8, device="cuda"); valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+ctxs = []
+for path in libs:
+    L = C.CDLL(path)
+    h = C.c_void_p()
+    L.p2e_ecdsa_verify_witness_batch.restype = C.c_long
+    assert L.p2e_ctx_create(C.c_int(0), C.c_uint(0), C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(h)) == 0
+    ctxs.append((L, h))
+def step(L, h):
+    rc = L.p2e_ecdsa_verify_witness_batch(h, *[C.c_void_p(d.data_ptr()) for d in dev], C.c_void_p(big.data_ptr()), C.c_size_t(n), C.c_size_t(ld),
+                                          C.c_void_p(err.data_ptr()), C.c_void_p(valid.data_ptr()))
+    assert rc == 0, rc
+res = {p: [] for p in libs}
+for L, h in ctxs:
+    step(L, h); step(L, h)
+torch.cuda.synchronize()
+for rnd in range(6):
+    for p, (L, h) in zip(libs, ctxs):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(5): step(L, h)
+        torch.cuda.synchronize(); res[p].append((time.perf_counter() - t) / 5 * 1e3)
+for p in libs:
+    r = sorted(res[p]); print(f"{os.path.basename(p):28s} median {r[len(r)//2]:.3f} ms  min {r[0]:.3f}  all {[round(x,2) for x in res[p]]}")
