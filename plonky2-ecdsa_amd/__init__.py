@@ -288,7 +288,11 @@ class Context:
         """verify_secp256k1_message_circuit (gadgets/ecdsa.rs:30-53): (82615, n) Goldilocks columns.
         ``cols`` may be a column slice of a wider matrix: pass its row stride as ``ld``."""
         n = self._shape(msg)[0]
-        cols = cols if cols is not None else self._cols(VERIFY_COLS, n)
+        if cols is None:
+            # a power-of-two column stride makes consecutive columns camp on the same HBM channels (-9 %)
+            ld = n + 16 if (n >= 4096 and n & (n - 1) == 0) else n
+            full = self._cols(VERIFY_COLS, ld)
+            cols = full[:, :n] if ld != n else full
         err = err if err is not None else self._vec(n, np.uint8)
         valid = valid if valid is not None else self._vec(n, np.uint8)
         ld = ld if ld is not None else self._shape(cols)[1]

@@ -45,12 +45,12 @@ __global__ __launch_bounds__(BS) void k_scalar(Program G, Buffers B, size_t firs
     }
 }
 // ops [lo, hi) of a chain, sequential per lane
-__global__ __launch_bounds__(BS) void k_chains(Program G, Buffers B, int lo, int hi) {
+__global__ __launch_bounds__(BS) void k_chains(Program G, Buffers B, int lo, int hi, int table_affine) {
     // the chain is the critical path of the whole call and shares its SIMD with phase B/C waves of
     // earlier pieces: win every issue arbitration against them
     __builtin_amdgcn_s_setprio(3);
     size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
-    if (i < B.n) body_chain_range(G, B, i, lo, hi);
+    if (i < B.n) body_chain_range(G, B, i, lo, hi, table_affine != 0);
 }
 // ops [lo, hi) in chunks of ch: blockIdx.y = chunk
 __global__ __launch_bounds__(BS) void k_batch_inv(Program G, Buffers B, int lo, int hi, int ch) {
@@ -256,7 +256,7 @@ struct p2e_ctx {
     double expand_cols[MAX_SEG] = {};
     float expand_ms_sum = 0.f;
     double expand_cols_sum = 0.0;
-    int msm_pieces = 6, fixed_pieces = 1, binv_target = BINV_TARGET_DEFAULT;
+    int msm_pieces = 8, fixed_pieces = 2, binv_target = BINV_TARGET_DEFAULT;
     Aff* d_cpts = nullptr;
     Aff* d_fbtab = nullptr;
     DeviceProgram progs[2];
@@ -776,15 +776,17 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     // chains
     for (int k = 0; k < ns; k++) {
         Seg& sg = segs[k];
-        hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, sg.hi);
+        // once the table piece has been inverted on this stream (below), later pieces read the table affine
+        const int table_affine = (sg.chain_stream == c->st_msm && k > first_msm && ns - first_msm > 1) ? 1 : 0;
+        hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, sg.hi, table_affine);
         if (verify && k == first_msm - 1) HIP_TRY(hipEventRecord(c->ev_fixed, c->st_fixed));
         if (sg.final_after) {
             HIP_TRY(hipStreamWaitEvent(c->st_msm, c->ev_fixed, 0));
-            hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, c->st_msm, G, B, G.chain_begin[2], G.chain_end[2]);
+            hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, c->st_msm, G, B, G.chain_begin[2], G.chain_end[2], 0);
             sg.hi = G.chain_end[2];
         }
         HIP_TRY(hipEventRecord(c->ev_piece[k], sg.chain_stream));
-        if (k == first_msm && ns > 1) {
+        if (k == first_msm && ns - first_msm > 1) {
             // The first MSM piece is the 23-op table build.  Its phase B runs right here on the chain's own
             // stream (the rest of the chain is not on the critical path: it ends long before the expansion
             // does), so that the first k_expand can start ~0.8 ms earlier than if it queued behind the
@@ -812,7 +814,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         // in order: a dedicated inversion stream ended up sharing the caller's queue and serialised B
         // with C.  The fixed-base chain's stream is idle after its first ~1 ms, so phase B lives there.
         hipStream_t st_b = c->st_fixed;
-        if (!(k == first_msm && ns > 1)) {
+        if (!(k == first_msm && ns - first_msm > 1)) {
             HIP_TRY(hipStreamWaitEvent(st_b, c->ev_piece[k], 0));
             hipLaunchKernelGGL(k_batch_inv, dim3(gx, nch), dim3(BS), 0, st_b, G, B, sg.lo, sg.hi, ch);
             HIP_TRY(hipEventRecord(c->ev_binv[k], st_b));

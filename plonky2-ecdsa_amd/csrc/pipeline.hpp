@@ -247,7 +247,10 @@ P2E_HD Aff load_fbtab(const Buffers& B, size_t i, u32 window, u32& digit) {
 }
 
 // ---- phase A: one op of a chain in Jacobian coordinates -----------------------------------------------
-P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t) {
+// table_affine: the MSM window table has already been through phase B (its 23-op piece is inverted before
+// the loop pieces start), so table operands are read in affine form and the 73 window additions are
+// mixed additions (11 multiplications instead of 17).
+P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, bool table_affine) {
     const OpDesc op = B.ops[t];
     size_t o = (size_t)t * B.n + i;
     JacW res;
@@ -260,20 +263,27 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t) {
         Jac p2;
         u32 digit = 1;
         uint16_t src2;
+        bool z2one = (op.flags & F_Z2ONE) != 0;
         if (ref_kind(op.ref2) == R_FBTAB) {
             Aff a = load_fbtab(B, i, ref_id(op.ref2), digit);
             p2 = jac_from_aff(a);
             src2 = (uint16_t)(SRC_FB_BIT | (ref_id(op.ref2) * 16 + digit));
         } else {
-            if (ref_kind(op.ref2) == R_MSMTAB) digit = B.dig2[(size_t)ref_id(op.ref2) * B.n + i];
+            const bool tab = ref_kind(op.ref2) == R_MSMTAB;
+            if (tab) digit = B.dig2[(size_t)ref_id(op.ref2) * B.n + i];
             src2 = resolve_src(G, B, i, op.ref2);
-            p2 = load_jac_src(B, i, src2, (op.flags & F_Z2ONE) != 0);
+            if (tab && table_affine) {
+                p2 = jac_from_aff(load_aff_src(B, i, src2));
+                z2one = true;
+            } else {
+                p2 = load_jac_src(B, i, src2, (op.flags & F_Z2ONE) != 0);
+            }
         }
         B.src[(size_t)(2 * t + 1) * B.n + i] = (uint16_t)(src2 | (digit != 0 ? SRC_SEL_BIT : 0));
         // the Z-one specialisations only skip multiplications by one: pick by the host-known flags
-        if ((op.flags & F_Z1ONE) && (op.flags & F_Z2ONE))
+        if ((op.flags & F_Z1ONE) && z2one)
             res = jac_add<true, true>(p1, p2);
-        else if (op.flags & F_Z2ONE)
+        else if (z2one)
             res = jac_add<false, true>(p1, p2);
         else if (op.flags & F_Z1ONE)
             res = jac_add<true, false>(p1, p2);
@@ -287,8 +297,8 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t) {
     B.PW[o] = res.W;
 }
 // ops [lo, hi) of one chain, in order (the range may be a piece of a chain: all state lives in scratch)
-P2E_HD void body_chain_range(const Program& G, const Buffers& B, size_t i, int lo, int hi) {
-    for (int t = lo; t < hi; t++) body_chain_op(G, B, i, t);
+P2E_HD void body_chain_range(const Program& G, const Buffers& B, size_t i, int lo, int hi, bool table_affine) {
+    for (int t = lo; t < hi; t++) body_chain_op(G, B, i, t, table_affine);
 }
 
 // ---- phase B: Montgomery batch inversion of Z over ops [t0, t1) of one signature ------------------------

@@ -46,9 +46,9 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
             for (long long i = 0; i < (long long)n; i++) body_batch_inv(G, B, (size_t)i, t0, t1);
         }
     };
-    auto chain = [&](int lo, int hi) {
+    auto chain = [&](int lo, int hi, bool table_affine) {
 #pragma omp parallel for
-        for (long long i = 0; i < (long long)n; i++) body_chain_range(G, B, (size_t)i, lo, hi);
+        for (long long i = 0; i < (long long)n; i++) body_chain_range(G, B, (size_t)i, lo, hi, table_affine);
     };
     auto expand = [&](int lo, int hi) {
 #pragma omp parallel for
@@ -57,22 +57,26 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     };
     const int pieces = 3;
     if (G.num_chains == 3) {
-        chain(G.chain_begin[1], G.chain_end[1]);
+        chain(G.chain_begin[1], G.chain_end[1], false);
         binv(G.chain_begin[1], G.chain_end[1]);
         expand(G.chain_begin[1], G.chain_end[1]);
     }
     {
+        // first piece = the 23-op window table, inverted before the loop pieces run (they then read it affine)
         int lo = G.chain_begin[0], hi = G.chain_end[0];
-        int per = (hi - lo + pieces - 1) / pieces;
-        for (int a = lo; a < hi; a += per) {
-            int b = a + per < hi ? a + per : hi;
-            chain(a, b);
+        int per = (hi - lo - 23 + pieces - 2) / (pieces - 1);
+        for (int a = lo; a < hi;) {
+            int b = a == lo ? lo + 23 : (a + per < hi ? a + per : hi);
+            chain(a, b, a != lo);
             if (b == hi && G.num_chains == 3) {
-                chain(G.chain_begin[2], G.chain_end[2]);
-                b = G.chain_end[2];
+                chain(G.chain_begin[2], G.chain_end[2], false);
+                binv(a, G.chain_end[2]);
+                expand(a, G.chain_end[2]);
+            } else {
+                binv(a, b);
+                expand(a, b);
             }
-            binv(a, b);
-            expand(a, b);
+            a = b;
         }
     }
     long bad = 0;
