@@ -21,7 +21,6 @@ using namespace p2e;
 // kernels
 // ====================================================================================================
 constexpr int BS = 256;          // 4 waves per workgroup
-constexpr int BINV_TARGET_DEFAULT = 64;  // ~curve ops per Montgomery batch (one Fermat ladder each)
 
 // Signature owned by this lane.  WIDE kernels (full workgroups only) give lanes l and l+32 of a wave
 // adjacent signatures so that column pairs can be written with 16-byte stores (PairEmit); the narrow
@@ -45,19 +44,17 @@ __global__ __launch_bounds__(BS) void k_scalar(Program G, Buffers B, size_t firs
     }
 }
 // ops [lo, hi) of a chain, sequential per lane
-__global__ __launch_bounds__(BS) void k_chains(Program G, Buffers B, int lo, int hi, int table_affine) {
+__global__ __launch_bounds__(BS) void k_chains(Program G, Buffers B, int lo, int hi, int table_affine, int continue_prefix) {
     // the chain is the critical path of the whole call and shares its SIMD with phase B/C waves of
     // earlier pieces: win every issue arbitration against them
     __builtin_amdgcn_s_setprio(3);
     size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
-    if (i < B.n) body_chain_range(G, B, i, lo, hi, table_affine != 0);
+    if (i < B.n) body_chain_range(G, B, i, lo, hi, table_affine != 0, continue_prefix != 0);
 }
-// ops [lo, hi) in chunks of ch: blockIdx.y = chunk
-__global__ __launch_bounds__(BS) void k_batch_inv(Program G, Buffers B, int lo, int hi, int ch) {
+// one inversion batch: ops [lo, hi), whose prefix products phase A has already left in PREF
+__global__ __launch_bounds__(BS) void k_batch_inv(Program G, Buffers B, int lo, int hi) {
     size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
-    int t0 = lo + (int)blockIdx.y * ch;
-    int t1 = t0 + ch < hi ? t0 + ch : hi;
-    if (i < B.n) body_batch_inv(G, B, i, t0, t1);
+    if (i < B.n) body_batch_inv(G, B, i, lo, hi, true);
 }
 // op lo + blockIdx.y
 template <bool WIDE>
@@ -256,7 +253,7 @@ struct p2e_ctx {
     double expand_cols[MAX_SEG] = {};
     float expand_ms_sum = 0.f;
     double expand_cols_sum = 0.0;
-    int msm_pieces = 8, fixed_pieces = 2, binv_target = BINV_TARGET_DEFAULT;
+    int msm_pieces = 8, fixed_pieces = 2;   // one Montgomery inversion batch per piece
     Aff* d_cpts = nullptr;
     Aff* d_fbtab = nullptr;
     DeviceProgram progs[2];
@@ -377,10 +374,6 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     if (const char* env = getenv("P2E_MSM_PIECES")) {
         int v = atoi(env);
         if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->msm_pieces = v;
-    }
-    if (const char* env = getenv("P2E_BINV_TARGET")) {
-        int v = atoi(env);
-        if (v >= 1 && v <= 512) c->binv_target = v;
     }
     if (const char* env = getenv("P2E_FIXED_PIECES")) {
         int v = atoi(env);
@@ -778,11 +771,12 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         Seg& sg = segs[k];
         // once the table piece has been inverted on this stream (below), later pieces read the table affine
         const int table_affine = (sg.chain_stream == c->st_msm && k > first_msm && ns - first_msm > 1) ? 1 : 0;
-        hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, sg.hi, table_affine);
+        hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, sg.hi, table_affine, 0);
         if (verify && k == first_msm - 1) HIP_TRY(hipEventRecord(c->ev_fixed, c->st_fixed));
         if (sg.final_after) {
             HIP_TRY(hipStreamWaitEvent(c->st_msm, c->ev_fixed, 0));
-            hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, c->st_msm, G, B, G.chain_begin[2], G.chain_end[2], 0);
+            // the final add joins the inversion batch of the last MSM piece
+            hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, c->st_msm, G, B, G.chain_begin[2], G.chain_end[2], 0, 1);
             sg.hi = G.chain_end[2];
         }
         HIP_TRY(hipEventRecord(c->ev_piece[k], sg.chain_stream));
@@ -791,7 +785,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             // stream (the rest of the chain is not on the critical path: it ends long before the expansion
             // does), so that the first k_expand can start ~0.8 ms earlier than if it queued behind the
             // fixed-base chain on the other stream.
-            hipLaunchKernelGGL(k_batch_inv, dim3(gx, 1), dim3(BS), 0, c->st_msm, G, B, sg.lo, sg.hi, sg.hi - sg.lo);
+            hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, c->st_msm, G, B, sg.lo, sg.hi);
             HIP_TRY(hipEventRecord(c->ev_binv[k], c->st_msm));
         }
     }
@@ -808,15 +802,13 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     for (int q = 0; q < ns; q++) {
         const int k = order[q];
         const Seg& sg = segs[k];
-        unsigned nch = (unsigned)((sg.hi - sg.lo + c->binv_target - 1) / c->binv_target);
-        int ch = (sg.hi - sg.lo + (int)nch - 1) / (int)nch;
         // HIP multiplexes streams onto a few hardware queues (4 by default) and kernels of one queue run
         // in order: a dedicated inversion stream ended up sharing the caller's queue and serialised B
         // with C.  The fixed-base chain's stream is idle after its first ~1 ms, so phase B lives there.
         hipStream_t st_b = c->st_fixed;
         if (!(k == first_msm && ns - first_msm > 1)) {
             HIP_TRY(hipStreamWaitEvent(st_b, c->ev_piece[k], 0));
-            hipLaunchKernelGGL(k_batch_inv, dim3(gx, nch), dim3(BS), 0, st_b, G, B, sg.lo, sg.hi, ch);
+            hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, st_b, G, B, sg.lo, sg.hi);
             HIP_TRY(hipEventRecord(c->ev_binv[k], st_b));
         }
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_binv[k], 0));

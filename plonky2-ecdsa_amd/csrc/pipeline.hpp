@@ -247,15 +247,34 @@ P2E_HD Aff load_fbtab(const Buffers& B, size_t i, u32 window, u32& digit) {
 }
 
 // ---- phase A: one op of a chain in Jacobian coordinates -----------------------------------------------
+// State a lane carries from op to op of a chain range: the previous op's result and first operand (the next
+// op's first operand is one of the two in 310 of 311 ops: a doubling after a doubling, the selected result
+// of a conditional add) and the running product of the Z3 values (the forward half of the Montgomery
+// batch inversion, so that phase B only runs the backward half).
+struct ChainState {
+    Jac out, p1;
+    uint16_t out_id, p1_id;
+    U256 acc;
+};
+P2E_HD Jac jac_select3(bool c1, const Jac& a, bool c2, const Jac& b, const Jac& c) {
+    Jac r;
+    r.X = u256_select(c1, a.X, u256_select(c2, b.X, c.X));
+    r.Y = u256_select(c1, a.Y, u256_select(c2, b.Y, c.Y));
+    r.Z = u256_select(c1, a.Z, u256_select(c2, b.Z, c.Z));
+    return r;
+}
 // table_affine: the MSM window table has already been through phase B (its 23-op piece is inverted before
 // the loop pieces start), so table operands are read in affine form and the 73 window additions are
 // mixed additions (11 multiplications instead of 17).
-P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, bool table_affine) {
+P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, bool table_affine, ChainState& st) {
     const OpDesc op = B.ops[t];
     size_t o = (size_t)t * B.n + i;
     JacW res;
     uint16_t src1 = resolve_src(G, B, i, op.ref1);
-    Jac p1 = load_jac_src(B, i, src1, (op.flags & F_Z1ONE) != 0);
+    const bool from_out = src1 == st.out_id, from_p1 = src1 == st.p1_id;
+    Jac p1 = st.out;
+    if (!(from_out || from_p1)) p1 = load_jac_src(B, i, src1, (op.flags & F_Z1ONE) != 0);
+    p1 = jac_select3(from_out, st.out, from_p1, st.p1, p1);
     B.src[(size_t)(2 * t) * B.n + i] = src1;
     if (op.kind == OP_DBL) {
         res = jac_dbl(p1);
@@ -295,28 +314,56 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, b
     B.PY[o] = res.p.Y;
     B.PZ[o] = res.p.Z;
     B.PW[o] = res.W;
+    // forward half of the batch inversion of this range
+    B.PREF[o] = st.acc;
+    U256 z = res.p.Z;
+    if (u256_is_zero(z)) {  // reference: inverse() of zero panics (gadgets/nonnative.rs:863)
+        err_or(&B.err[i], ERR_INVERSE_OF_ZERO);
+        z = u256_small(1);
+    }
+    st.acc = fp_mul(st.acc, z);
+    st.p1 = p1;
+    st.p1_id = (op.flags & F_Z1ONE) ? (uint16_t)0xFFFF : src1;   // an affine operand has no Z to carry
+    st.out = res.p;
+    st.out_id = (uint16_t)t;
 }
-// ops [lo, hi) of one chain, in order (the range may be a piece of a chain: all state lives in scratch)
-P2E_HD void body_chain_range(const Program& G, const Buffers& B, size_t i, int lo, int hi, bool table_affine) {
-    for (int t = lo; t < hi; t++) body_chain_op(G, B, i, t, table_affine);
+// Product of the Z3 values (zeros replaced by one) of ops [lo, hi) given the prefix array: prefix of the
+// last op times its own Z3.
+P2E_HD U256 range_product(const Buffers& B, size_t i, int last) {
+    size_t o = (size_t)last * B.n + i;
+    U256 z = B.PZ[o];
+    if (u256_is_zero(z)) z = u256_small(1);
+    return fp_mul(B.PREF[o], z);
+}
+// ops [lo, hi) of one chain, in order (the range may be a piece of a chain: everything a later piece needs
+// lives in scratch).  continue_prefix: the range extends the inversion batch of the ops just before it.
+P2E_HD void body_chain_range(const Program& G, const Buffers& B, size_t i, int lo, int hi, bool table_affine,
+                             bool continue_prefix) {
+    ChainState st;
+    st.out_id = st.p1_id = 0xFFFF;
+    st.out.X = st.out.Y = st.out.Z = st.p1.X = st.p1.Y = st.p1.Z = u256_zero();
+    st.acc = continue_prefix ? range_product(B, i, lo - 1) : u256_small(1);
+    for (int t = lo; t < hi; t++) body_chain_op(G, B, i, t, table_affine, st);
 }
 
 // ---- phase B: Montgomery batch inversion of Z over ops [t0, t1) of one signature ------------------------
 // Reads the Jacobian results (left intact: later pieces of the chain still consume them), writes the
-// affine points to AX/AY and v^-1 over W.
-P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0, int t1) {
+// affine points to AX/AY and v^-1 over W.  have_prefix: [t0, t1) is exactly one inversion batch of phase A,
+// whose prefix products are already in PREF (the normal case); otherwise the forward pass runs here.
+P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0, int t1, bool have_prefix) {
     (void)G;
-    uint8_t err = 0;
-    U256 acc = u256_small(1);
-    for (int t = t0; t < t1; t++) {
-        size_t o = (size_t)t * B.n + i;
-        U256 z = B.PZ[o];
-        if (u256_is_zero(z)) {  // reference: inverse() of zero panics (gadgets/nonnative.rs:863)
-            err |= ERR_INVERSE_OF_ZERO;
-            z = u256_small(1);
+    U256 acc;
+    if (have_prefix) {
+        acc = range_product(B, i, t1 - 1);
+    } else {
+        acc = u256_small(1);
+        for (int t = t0; t < t1; t++) {
+            size_t o = (size_t)t * B.n + i;
+            U256 z = B.PZ[o];
+            if (u256_is_zero(z)) z = u256_small(1);   // flagged by phase A
+            B.PREF[o] = acc;
+            acc = fp_mul(acc, z);
         }
-        B.PREF[o] = acc;
-        acc = fp_mul(acc, z);
     }
     U256 inv = fe_inv<ModP>(acc);
     for (int t = t1 - 1; t >= t0; t--) {
@@ -331,7 +378,6 @@ P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0,
         B.AY[o] = fp_mul(B.PY[o], zi3);
         B.PW[o] = fp_mul(B.PW[o], zi);  // v^-1 of op t
     }
-    if (err) err_or(&B.err[i], err);
 }
 
 // ---- phase C: witness columns of one curve op ---------------------------------------------------------------

@@ -39,16 +39,23 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     for (long long i = 0; i < (long long)n; i++) body_scalar<Emit>(G, B, (size_t)i);
     // same dependency order as the stream plan of p2e_hip.hip, with the MSM chain cut into `pieces` pieces whose
     // phases B and C are interleaved with the following pieces of the chain
+    // chunk >= piece length: one batch per piece using phase A's prefix products (what the GPU launches);
+    // smaller chunks re-run the forward pass inside phase B (arbitrary batching must not change any output)
     auto binv = [&](int lo, int hi) {
+        if (chunk >= hi - lo) {
+#pragma omp parallel for
+            for (long long i = 0; i < (long long)n; i++) body_batch_inv(G, B, (size_t)i, lo, hi, true);
+            return;
+        }
         for (int t0 = lo; t0 < hi; t0 += chunk) {
             int t1 = t0 + chunk < hi ? t0 + chunk : hi;
 #pragma omp parallel for
-            for (long long i = 0; i < (long long)n; i++) body_batch_inv(G, B, (size_t)i, t0, t1);
+            for (long long i = 0; i < (long long)n; i++) body_batch_inv(G, B, (size_t)i, t0, t1, false);
         }
     };
-    auto chain = [&](int lo, int hi, bool table_affine) {
+    auto chain = [&](int lo, int hi, bool table_affine, bool cont = false) {
 #pragma omp parallel for
-        for (long long i = 0; i < (long long)n; i++) body_chain_range(G, B, (size_t)i, lo, hi, table_affine);
+        for (long long i = 0; i < (long long)n; i++) body_chain_range(G, B, (size_t)i, lo, hi, table_affine, cont);
     };
     auto expand = [&](int lo, int hi) {
 #pragma omp parallel for
@@ -69,7 +76,7 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
             int b = a == lo ? lo + 23 : (a + per < hi ? a + per : hi);
             chain(a, b, a != lo);
             if (b == hi && G.num_chains == 3) {
-                chain(G.chain_begin[2], G.chain_end[2], false);
+                chain(G.chain_begin[2], G.chain_end[2], false, true);
                 binv(a, G.chain_end[2]);
                 expand(a, G.chain_end[2]);
             } else {
