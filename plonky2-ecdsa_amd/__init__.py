@@ -300,13 +300,13 @@ class Context:
                                                                  _ptr(cols), C.c_size_t(n), C.c_size_t(ld), _ptr(err), _ptr(valid)))
         return cols, err, valid, bad
 
-    def glv_mul_witness_batch(self, px, py, k, cols=None, err=None, valid=None):
+    def glv_mul_witness_batch(self, px, py, k, cols=None, err=None, valid=None, ld=None):
         """glv_mul (gadgets/glv.rs:87-104): (65243, n) Goldilocks columns."""
         n = self._shape(px)[0]
         cols = cols if cols is not None else self._cols(GLV_MUL_COLS, n)
         err = err if err is not None else self._vec(n, np.uint8)
         valid = valid if valid is not None else self._vec(n, np.uint8)
-        ld = self._shape(cols)[1]
+        ld = ld if ld is not None else self._shape(cols)[1]
         bad = self._check(self._L.p2e_glv_mul_witness_batch(self._h, _ptr(px), _ptr(py), _ptr(k), _ptr(cols),
                                                             C.c_size_t(n), C.c_size_t(ld), _ptr(err), _ptr(valid)))
         return cols, err, valid, bad

@@ -29,7 +29,7 @@ def timed(fn):
     return s.elapsed_time(e) / reps
 
 
-which = sys.argv[1:] or ["split", "mul", "transpose"]
+which = sys.argv[1:] or ["split", "mul", "transpose", "glv"]
 if "split" in which:
     for lg in (20, 24, 26):
         n = 1 << lg
@@ -62,3 +62,17 @@ if "transpose" in which:
     b = 2 * 8 * n * p2e.VERIFY_COLS
     print(json.dumps({"kernel": "k_transpose", "n": n, "ncols": p2e.VERIFY_COLS, "ms": round(ms, 4), "alg_bytes": b,
                       "GBps": round(b / ms / 1e6, 1), "frac_hbm_peak": round(b / ms / 1e6 / PEAK, 4)}), flush=True)
+if "glv" in which:
+    # BASELINE config 3: glv_mul witness fills (65 243 columns each), 2^10 (latency-bound) and 2^16
+    import plonky2_ecdsa_amd as _p
+    for lg in (10, 16):
+        n = 1 << lg
+        sig = _p.synth_signatures(seed=3, n=n)
+        px, py, k = [torch.from_numpy(a).cuda() for a in (sig[3], sig[4], sig[0])]
+        ld = n + 16
+        cols = torch.empty((_p.GLV_MUL_COLS, ld), dtype=torch.int64, device="cuda")
+        ms = timed(lambda: ctx.glv_mul_witness_batch(px, py, k, cols=cols[:, :n], ld=ld))
+        b = n * (_p.GLV_MUL_COLS * 8 + 96)
+        print(json.dumps({"kernel": "glv_mul pipeline", "n": n, "ms": round(ms, 4), "fills_per_s": round(n / ms * 1e3, 1),
+                          "alg_bytes": b, "GBps": round(b / ms / 1e6, 1), "frac_hbm_peak": round(b / ms / 1e6 / PEAK, 4)}), flush=True)
+        del cols
