@@ -261,7 +261,7 @@ struct p2e_ctx {
     size_t scratch_bytes = 0;
     unsigned long long* d_counter = nullptr;
     unsigned long long* h_counter = nullptr;  // pinned
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[6] = {};   // [0],[1] around k_scalar, [5] end of the call (2..4 unused)
     float phase_ms[5] = {0, 0, 0, 0, 0};
     bool have_phases = false;
 };
@@ -732,7 +732,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     const unsigned gx_tail = (unsigned)((n - n_wide + BS - 1) / BS);
     // ---- launch plan ------------------------------------------------------------------------------------
     // chains (latency-bound, sequential) : their own high-priority streams, cut into pieces
-    // phase B of a piece                 : st_binv, as soon as the piece's chain kernel is done (ALU-bound)
+    // phase B of a piece                 : the fixed-base chain's stream, once the piece's chain kernel is done
     // phase C of a piece                 : the caller's stream, after its phase B (HBM-bound)
     // so that the HBM-bound expansion of finished pieces hides the chains and inversions of later ones.
     struct Seg {
