@@ -1,4 +1,6 @@
-"""experiment: time the pipeline with a library build whose column stores are predicated off (ALU-only)"""
+"""Experiment behind DESIGN.md section 5 (iii): time the pipeline with an alternative build of libp2e_hip.so
+(argv[1]), e.g. one whose column stores are predicated off (PairEmit::store_* guarded by an impossible value):
+ALU-only time of every kernel.  Build such a variant from a scratch copy of csrc/, never commit it."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

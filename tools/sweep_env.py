@@ -12,8 +12,8 @@ ld = n + 16
 big = torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device="cuda")
 err = torch.empty(n, dtype=torch.uint8, device="cuda"); valid = torch.empty(n, dtype=torch.uint8, device="cuda")
 settings = []
-for binv, msm, fx in itertools.product((64, 32, 22, 16), (4, 6, 8, 12), (1, 2)):
-    settings.append({"P2E_BINV_TARGET": str(binv), "P2E_MSM_PIECES": str(msm), "P2E_FIXED_PIECES": str(fx)})
+for msm, fx in itertools.product((1, 2, 4, 6, 8, 10, 12), (1, 2, 3)):
+    settings.append({"P2E_MSM_PIECES": str(msm), "P2E_FIXED_PIECES": str(fx)})
 ctxs = []
 for s in settings:
     os.environ.update(s)
