@@ -66,6 +66,18 @@ __global__ __launch_bounds__(BS) void k_expand(Program G, Buffers B, int lo, siz
         body_expand<Emit>(G, B, i, lo + (int)blockIdx.y);
     }
 }
+// runs of MSM-loop iterations: run blockIdx.y of the launch covers iterations [it_first + y*R, +R) capped at it_end
+template <bool WIDE>
+__global__ __launch_bounds__(BS) void k_expand_runs(Program G, Buffers B, int it_first, int run_iters, int it_end, size_t first) {
+    size_t i = lane_sig<WIDE>(first);
+    int it0 = it_first + (int)blockIdx.y * run_iters;
+    int it1 = it0 + run_iters < it_end ? it0 + run_iters : it_end;
+    if (WIDE) {
+        body_expand_run<PairEmit>(G, B, i, it0, it1);
+    } else if (i < B.n) {
+        body_expand_run<Emit>(G, B, i, it0, it1);
+    }
+}
 // err words -> caller's err bytes, valid bytes, flagged count
 __global__ __launch_bounds__(BS) void k_finalize(const u32* err32, const uint8_t* valid8, uint8_t* err_out,
                                                  uint8_t* valid_out, size_t n, unsigned long long* counter) {
@@ -254,6 +266,7 @@ struct p2e_ctx {
     float expand_ms_sum = 0.f;
     double expand_cols_sum = 0.0;
     int msm_pieces = 8, fixed_pieces = 2;   // one Montgomery inversion batch per piece
+    int run_iters = 9;                      // MSM-loop iterations per expansion run (0: expand op by op)
     Aff* d_cpts = nullptr;
     Aff* d_fbtab = nullptr;
     DeviceProgram progs[2];
@@ -281,12 +294,13 @@ static const DeviceProgram& host_program(int program) {
     });
     return P[program];
 }
-static std::vector<OpDesc> host_ops(int program) {
+static std::vector<OpDesc> host_ops(int program, int run_iters) {
     host::ScheduleBuilder b;
     if (program == 0)
         b.verify_secp256k1_message_circuit();
     else
         b.glv_mul_circuit();
+    b.mark_runs(run_iters);
     return b.ops;
 }
 
@@ -351,9 +365,13 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     HIP_TRY(hipMalloc(&c->d_fbtab, sizeof(Aff) * C.fbtab.size()));
     HIP_TRY(hipMemcpy(c->d_cpts, C.cpts, sizeof(Aff) * NUM_CONST_PTS, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_fbtab, C.fbtab.data(), sizeof(Aff) * C.fbtab.size(), hipMemcpyHostToDevice));
+    if (const char* env = getenv("P2E_RUN_ITERS")) {
+        int v = atoi(env);
+        if (v >= 0 && v <= MSM_DIGITS) c->run_iters = v;
+    }
     for (int p = 0; p < 2; p++) {
         c->progs[p].prog = host_program(p).prog;
-        std::vector<OpDesc> ops = host_ops(p);
+        std::vector<OpDesc> ops = host_ops(p, c->run_iters);
         c->progs[p].h_ops = ops;
         HIP_TRY(hipMalloc(&c->progs[p].d_ops, sizeof(OpDesc) * ops.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_ops, ops.data(), sizeof(OpDesc) * ops.size(), hipMemcpyHostToDevice));
@@ -736,27 +754,57 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     // phase C of a piece                 : the caller's stream, after its phase B (HBM-bound)
     // so that the HBM-bound expansion of finished pieces hides the chains and inversions of later ones.
     struct Seg {
-        int lo, hi, order;   // ops, readiness estimate (ops walked on its chain before it completes)
+        int lo, hi, order;   // ops for phases A and B; readiness estimate (ops walked on its chain before it completes)
         hipStream_t chain_stream;
         bool final_after;    // append the final add (needs the fixed-base chain) to this piece
+        int s_lo, s_hi;      // ops expanded one by one (k_expand)
+        int it0, it1;        // MSM-loop iterations expanded as runs (k_expand_runs)
     };
     Seg segs[p2e_ctx::MAX_SEG];
     int ns = 0;
     const bool verify = G.num_chains == 3;
-    auto cut = [&](int lo, int hi, int pieces, hipStream_t st, bool small_first) {
+    auto cut = [&](int lo, int hi, int pieces, hipStream_t st) {
         if (pieces > hi - lo) pieces = hi - lo;
         int a = lo;
         for (int k = 0; k < pieces; k++) {
             int rem = pieces - k;
             int len = (hi - a + rem - 1) / rem;
-            if (small_first && k == 0 && pieces > 1 && len > 23) len = 23;   // MSM table build: first C early
-            segs[ns++] = Seg{a, a + len, a + len - lo, st, false};
+            segs[ns++] = Seg{a, a + len, a + len - lo, st, false, a, a + len, 0, 0};
             a += len;
         }
     };
-    if (verify) cut(G.chain_begin[1], G.chain_end[1], c->fixed_pieces, c->st_fixed, false);
-    int first_msm = ns;
-    cut(G.chain_begin[0], G.chain_end[0], c->msm_pieces, c->st_msm, true);
+    if (verify) cut(G.chain_begin[1], G.chain_end[1], c->fixed_pieces, c->st_fixed);
+    const int first_msm = ns;
+    {
+        // MSM chain = window table (its own piece: inverted first, read in affine form by everything after) +
+        // the loop, cut at run boundaries into msm_pieces - 1 groups + the trailing unblinding add
+        const int lo0 = G.chain_begin[0], hi0 = G.chain_end[0];
+        const int lb = G.msm_loop_begin, iters = G.msm_loop_iters, le = lb + 3 * iters;
+        const int R = c->run_iters > 0 ? c->run_iters : 1;
+        const int nruns = (iters + R - 1) / R;
+        int groups = c->msm_pieces > 1 ? c->msm_pieces - 1 : 1;
+        if (groups > nruns) groups = nruns;
+        segs[ns++] = Seg{lo0, lb, lb - lo0, c->st_msm, false, lo0, lb, 0, 0};
+        int run = 0;
+        for (int g = 0; g < groups; g++) {
+            int rem = groups - g;
+            int take = (nruns - run + rem - 1) / rem;
+            int it0 = run * R, it1 = (run + take) * R < iters ? (run + take) * R : iters;
+            Seg sg{lb + 3 * it0, lb + 3 * it1, lb + 3 * it1 - lo0, c->st_msm, false, 0, 0, it0, it1};
+            if (c->run_iters == 0) {   // run expansion disabled: op by op
+                sg.s_lo = sg.lo;
+                sg.s_hi = sg.hi;
+                sg.it0 = sg.it1 = 0;
+            }
+            if (g == groups - 1) {     // trailing ops of the chain (the unblinding add)
+                sg.hi = hi0;
+                if (c->run_iters == 0) sg.s_hi = hi0; else { sg.s_lo = le; sg.s_hi = hi0; }
+                sg.order = hi0 - lo0;
+            }
+            segs[ns++] = sg;
+            run += take;
+        }
+    }
     if (verify) segs[ns - 1].final_after = true;
 
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
@@ -770,7 +818,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     for (int k = 0; k < ns; k++) {
         Seg& sg = segs[k];
         // once the table piece has been inverted on this stream (below), later pieces read the table affine
-        const int table_affine = (sg.chain_stream == c->st_msm && k > first_msm && ns - first_msm > 1) ? 1 : 0;
+        const int table_affine = (sg.chain_stream == c->st_msm && k > first_msm) ? 1 : 0;
         hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, sg.hi, table_affine, 0);
         if (verify && k == first_msm - 1) HIP_TRY(hipEventRecord(c->ev_fixed, c->st_fixed));
         if (sg.final_after) {
@@ -778,9 +826,10 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             // the final add joins the inversion batch of the last MSM piece
             hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, c->st_msm, G, B, G.chain_begin[2], G.chain_end[2], 0, 1);
             sg.hi = G.chain_end[2];
+            sg.s_hi = G.chain_end[2];
         }
         HIP_TRY(hipEventRecord(c->ev_piece[k], sg.chain_stream));
-        if (k == first_msm && ns - first_msm > 1) {
+        if (k == first_msm) {
             // The first MSM piece is the 23-op table build.  Its phase B runs right here on the chain's own
             // stream (the rest of the chain is not on the critical path: it ends long before the expansion
             // does), so that the first k_expand can start ~0.8 ms earlier than if it queued behind the
@@ -806,7 +855,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         // in order: a dedicated inversion stream ended up sharing the caller's queue and serialised B
         // with C.  The fixed-base chain's stream is idle after its first ~1 ms, so phase B lives there.
         hipStream_t st_b = c->st_fixed;
-        if (!(k == first_msm && ns - first_msm > 1)) {
+        if (k != first_msm) {
             HIP_TRY(hipStreamWaitEvent(st_b, c->ev_piece[k], 0));
             hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, st_b, G, B, sg.lo, sg.hi);
             HIP_TRY(hipEventRecord(c->ev_binv[k], st_b));
@@ -814,10 +863,20 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_binv[k], 0));
         int e = c->n_expand++;
         HIP_TRY(hipEventRecord(c->ev_c0[e], c->stream));
-        if (gx_wide)
-            hipLaunchKernelGGL(k_expand<true>, dim3(gx_wide, (unsigned)(sg.hi - sg.lo)), dim3(BS), 0, c->stream, G, B, sg.lo, (size_t)0);
-        if (gx_tail)
-            hipLaunchKernelGGL(k_expand<false>, dim3(gx_tail, (unsigned)(sg.hi - sg.lo)), dim3(BS), 0, c->stream, G, B, sg.lo, n_wide);
+        if (sg.it1 > sg.it0) {
+            const int R = c->run_iters;
+            const unsigned nr = (unsigned)((sg.it1 - sg.it0 + R - 1) / R);
+            if (gx_wide)
+                hipLaunchKernelGGL(k_expand_runs<true>, dim3(gx_wide, nr), dim3(BS), 0, c->stream, G, B, sg.it0, R, sg.it1, (size_t)0);
+            if (gx_tail)
+                hipLaunchKernelGGL(k_expand_runs<false>, dim3(gx_tail, nr), dim3(BS), 0, c->stream, G, B, sg.it0, R, sg.it1, n_wide);
+        }
+        if (sg.s_hi > sg.s_lo) {
+            if (gx_wide)
+                hipLaunchKernelGGL(k_expand<true>, dim3(gx_wide, (unsigned)(sg.s_hi - sg.s_lo)), dim3(BS), 0, c->stream, G, B, sg.s_lo, (size_t)0);
+            if (gx_tail)
+                hipLaunchKernelGGL(k_expand<false>, dim3(gx_tail, (unsigned)(sg.s_hi - sg.s_lo)), dim3(BS), 0, c->stream, G, B, sg.s_lo, n_wide);
+        }
         HIP_TRY(hipEventRecord(c->ev_c1[e], c->stream));
         double cols_written = 0;
         for (int t = sg.lo; t < sg.hi; t++)

@@ -19,7 +19,9 @@ namespace p2e {
 // ---- schedule description shared by host and device ---------------------------------------------------
 enum OpKind : uint8_t { OP_ADD = 0, OP_DBL = 1, OP_CADD = 2 };
 enum RefKind : uint32_t { R_SLOT = 0, R_CONST = 1, R_DYN = 2, R_FBTAB = 3, R_MSMTAB = 4 };
-enum OpFlags : uint8_t { F_Z1ONE = 1, F_Z2ONE = 2, F_CHECK_R = 4 };
+// F_NO_AFFINE: the op's result is only ever consumed inside an expansion run (run-walked in registers by
+// k_expand_runs), so phase B skips its Jacobian -> affine conversion
+enum OpFlags : uint8_t { F_Z1ONE = 1, F_Z2ONE = 2, F_CHECK_R = 4, F_NO_AFFINE = 8 };
 P2E_HD constexpr u32 make_ref(u32 kind, u32 id) { return (kind << 24) | id; }
 P2E_HD constexpr u32 ref_kind(u32 r) { return r >> 24; }
 P2E_HD constexpr u32 ref_id(u32 r) { return r & 0xFFFFFFu; }
@@ -62,6 +64,8 @@ struct Program {
     // chain 0, own stream), 2 = final add (needs both).  glv_mul: 0 = the whole schedule.
     int32_t num_chains;
     int32_t chain_begin[4], chain_end[4];
+    // the MSM loop: msm_loop_iters iterations of (double, double, conditional add) starting at op msm_loop_begin
+    int32_t msm_loop_begin, msm_loop_iters;
 };
 
 struct Buffers {
@@ -310,8 +314,12 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, b
             res = jac_add<false, false>(p1, p2);
         if (op.kind == OP_CADD) B.dyn[(size_t)op.cadd_idx * B.n + i] = digit != 0 ? (uint16_t)t : src1;
     }
-    B.PX[o] = res.p.X;
-    B.PY[o] = res.p.Y;
+    // X, Y of a result are read back only by phase B's affine conversion and by the first op of a later chain
+    // piece; pieces are cut at run boundaries, whose two candidate results always keep their affine form
+    if (!(op.flags & F_NO_AFFINE)) {
+        B.PX[o] = res.p.X;
+        B.PY[o] = res.p.Y;
+    }
     B.PZ[o] = res.p.Z;
     B.PW[o] = res.W;
     // forward half of the batch inversion of this range
@@ -372,11 +380,13 @@ P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0,
         if (u256_is_zero(z)) z = u256_small(1);
         U256 zi = fp_mul(inv, B.PREF[o]);
         inv = fp_mul(inv, z);
-        U256 zi2 = fp_sqr(zi);
-        U256 zi3 = fp_mul(zi2, zi);
-        B.AX[o] = fp_mul(B.PX[o], zi2);
-        B.AY[o] = fp_mul(B.PY[o], zi3);
         B.PW[o] = fp_mul(B.PW[o], zi);  // v^-1 of op t
+        if (!(B.ops[t].flags & F_NO_AFFINE)) {
+            U256 zi2 = fp_sqr(zi);
+            U256 zi3 = fp_mul(zi2, zi);
+            B.AX[o] = fp_mul(B.PX[o], zi2);
+            B.AY[o] = fp_mul(B.PY[o], zi3);
+        }
     }
 }
 
@@ -443,6 +453,40 @@ P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t) {
         }
     }
     e.flush();
+    if (err) err_or(&B.err[i], err);
+}
+
+// Phase C over a RUN of MSM-loop iterations [it0, it1): the lane walks double, double, conditional add ...
+// with the running point in registers (the affine results are by-products of the witness arithmetic), so per
+// op it only reads v^-1 (32 B) and, per iteration, one table point.  Phase B therefore converts only the two
+// candidates for the running point at the END of each run (F_NO_AFFINE on the rest).
+template <class E>
+P2E_HD void body_expand_run(const Program& G, const Buffers& B, size_t i, int it0, int it1) {
+    uint8_t err = 0;
+    int t = G.msm_loop_begin + 3 * it0;
+    Aff p = load_aff_src(B, i, B.src[(size_t)(2 * t) * B.n + i]);
+    for (int it = it0; it < it1; it++, t += 3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (int k = 0; k < 2; k++) {  // curve_repeated_double(result, 2)
+            E e = E::at(B.out, B.ld, i, B.ops[t + k].col);
+            p = wit_curve_double(e, p, B.PW[(size_t)(t + k) * B.n + i], err);
+            e.flush();
+        }
+        const int tc = t + 2;
+        const uint16_t s2 = B.src[(size_t)(2 * tc + 1) * B.n + i];
+        Aff p2 = load_aff_src(B, i, (uint16_t)(s2 & (DYN_CONST_BIT | SRC_ID_MASK)));
+        const bool b = (s2 & SRC_SEL_BIT) != 0;
+        E e = E::at(B.out, B.ld, i, B.ops[tc].col);
+        Aff sm = wit_curve_add(e, p, p2, B.PW[(size_t)tc * B.n + i], err);
+        const U256 z = u256_zero();
+        Aff nx;
+        nx.x = wit_add<ModP>(e, u256_select(b, sm.x, z), u256_select(b, z, p.x));
+        nx.y = wit_add<ModP>(e, u256_select(b, sm.y, z), u256_select(b, z, p.y));
+        e.flush();
+        p = nx;
+    }
     if (err) err_or(&B.err[i], err);
 }
 

@@ -137,6 +137,8 @@ public:
         }
         for (int i = 0; i < 16; i++) prog.msm_tab[i] = pre[i].ref;
         AffinePointTarget result = rando;
+        prog.msm_loop_begin = (int32_t)ops.size();
+        prog.msm_loop_iters = MSM_DIGITS;
         for (int d = MSM_DIGITS - 1; d >= 0; d--) {
             Scope s(this, "digit" + std::to_string(d));
             result = curve_repeated_double(result, 2);
@@ -220,6 +222,22 @@ public:
         prog.chain_begin[0] = 0;
         prog.chain_end[0] = (int)ops.size();
         finish();
+    }
+
+    // Expansion runs of `run_iters` loop iterations: inside a run only the last (double, conditional add) pair
+    // can be the next run's starting point, every other result never needs affine coordinates in memory.
+    void mark_runs(int run_iters) {
+        for (auto& o : ops) o.flags &= (uint8_t)~F_NO_AFFINE;
+        if (run_iters < 1) return;
+        for (int it = 0; it < prog.msm_loop_iters; it++) {
+            const bool last_of_run = (it % run_iters) == run_iters - 1 || it == prog.msm_loop_iters - 1;
+            const int t = prog.msm_loop_begin + 3 * it;
+            ops[t].flags |= F_NO_AFFINE;
+            if (!last_of_run) {
+                ops[t + 1].flags |= F_NO_AFFINE;
+                ops[t + 2].flags |= F_NO_AFFINE;
+            }
+        }
     }
 
 private:

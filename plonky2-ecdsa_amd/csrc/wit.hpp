@@ -48,38 +48,50 @@ struct Emit {
 // base; the launcher falls back to Emit otherwise.  All bookkeeping below (column counters, "have a
 // pending value") is compile-time after inlining: every put sequence is static.
 struct PairEmit {
-    u64* base;    // &out[col0 * ld]
+    // All lane dependence lives in ONE running pointer that is bumped by the (wave-uniform) stride per column.
+    // Computing `out + (c + upper) * ld + sig` per store instead costs two quarter-rate v_mad_u64_u32 each and,
+    // inside the run-walking loop, makes the optimiser keep one hoisted VGPR per column constant of the body
+    // (349 registers, one wave per SIMD).
+    u64* two;         // this lane's 16-byte slot of the column pair (col - 1, col): lags the cursor by one column
+    ptrdiff_t delta;  // this lane's 8-byte slot of column c is (its 16-byte slot of pair (c, c+1)) + delta
     size_t ld;
-    size_t sig;   // this lane's signature
-    u32 upper;    // lane >> 5
-    int col;      // cursor, relative to col0
+    int col;          // cursor, relative to col0
     bool have, have2;
     u64 pend, pend2;
     int pcol, pcol2;
     P2E_HD static PairEmit at(u64* out, size_t ld_, size_t sig_, u32 col0) {
         PairEmit e;
-        e.base = out + (size_t)col0 * ld_;
+        const size_t upper = sig_ & 1;   // the lane mapping makes the signature's parity the half-wave index
+        // lower half-wave: column c of signatures (sig, sig+1); upper: column c+1 of (sig-1, sig)
+        uintptr_t first = (uintptr_t)(out + (size_t)col0 * ld_ + (upper ? ld_ : 0) + (sig_ - upper));
+        e.two = (u64*)(first - 8 * ld_);
+        e.delta = upper ? (ptrdiff_t)1 - (ptrdiff_t)ld_ : 0;
         e.ld = ld_;
-        e.sig = sig_;
-        e.upper = (u32)(sig_ & 1);   // the lane mapping makes the signature's parity the half-wave index
         e.col = 0;
         e.have = e.have2 = false;
         e.pend = e.pend2 = 0;
         e.pcol = e.pcol2 = 0;
         return e;
     }
+    P2E_HD u64* slot2(int c) const {   // c - (col - 1) is a compile-time constant at every call site
+        const int d = c - (col - 1);
+        return d == 0 ? two : (u64*)((uintptr_t)two + (intptr_t)d * (intptr_t)(8 * ld));
+    }
+    P2E_HD void bump(int k) {
+        two = (u64*)((uintptr_t)two + (size_t)k * 8 * ld);
+        asm("" : "+v"(two));   // keep it a running pointer: do not re-derive first + c * ld
+        col += k;
+    }
     // Output columns are write-once / never re-read by the pipeline: non-temporal stores keep them from
     // displacing the scratch arrays that phases B and C are about to read (-1.6 % on the whole step).
-    P2E_HD void store_single(int c, u64 v) { __builtin_nontemporal_store(v, base + (size_t)c * ld + sig); }
+    P2E_HD void store_single(int c, u64 v) { __builtin_nontemporal_store(v, slot2(c) + delta); }
     P2E_HD void store_pair(int c, u64 a, u64 b) {   // a: my value of column c, b: of column c + 1
         u32 ax = (u32)a, ay = (u32)(a >> 32), bx = (u32)b, by = (u32)(b >> 32);
         auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
         auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-        uint4 o = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-        u64* dst = base + (size_t)(c + (int)upper) * ld + (sig - upper);
         typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-        v4u ov = {o.x, o.y, o.z, o.w};
-        __builtin_nontemporal_store(ov, reinterpret_cast<v4u*>(dst));
+        v4u ov = {r0[0], r1[0], r0[1], r1[1]};
+        __builtin_nontemporal_store(ov, reinterpret_cast<v4u*>(slot2(c)));
     }
     P2E_HD void put(u64 v) {
         if (have && pcol + 1 == col) {
@@ -91,7 +103,7 @@ struct PairEmit {
             pcol = col;
             have = true;
         }
-        col++;
+        bump(1);
     }
     P2E_HD void put_at(int k, u64 v) {
         const int c = col + k;
@@ -105,7 +117,7 @@ struct PairEmit {
             have2 = true;
         }
     }
-    P2E_HD void skip(int k) { col += k; }
+    P2E_HD void skip(int k) { bump(k); }
     P2E_HD void flush() {
         if (have) store_single(pcol, pend);
         if (have2) store_single(pcol2, pend2);

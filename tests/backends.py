@@ -107,18 +107,20 @@ class EmuBackend:
         self.L.emu_pack(_p(limbs), _p(out), C.c_size_t(n), C.c_size_t(n), _p(err))
         return out, err
 
-    def verify(self, msg, r, s, pkx, pky, chunk=512):
+    def verify(self, msg, r, s, pkx, pky, chunk=512, run_iters=4):
         arrs = [np.ascontiguousarray(a, np.uint8) for a in (msg, r, s, pkx, pky)]
         n = arrs[0].shape[0]
         cols, err, valid = _z(82615, n), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
-        self.L.emu_verify(*[_p(a) for a in arrs], _p(cols), C.c_size_t(n), C.c_size_t(n), _p(err), _p(valid), C.c_int(chunk))
+        self.L.emu_verify(*[_p(a) for a in arrs], _p(cols), C.c_size_t(n), C.c_size_t(n), _p(err), _p(valid), C.c_int(chunk),
+                          C.c_int(run_iters))
         return cols, err, valid
 
-    def glv_mul(self, px, py, k, chunk=512):
+    def glv_mul(self, px, py, k, chunk=512, run_iters=4):
         arrs = [np.ascontiguousarray(a, np.uint8) for a in (px, py, k)]
         n = arrs[0].shape[0]
         cols, err, valid = _z(65243, n), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
-        self.L.emu_glv_mul(*[_p(a) for a in arrs], _p(cols), C.c_size_t(n), C.c_size_t(n), _p(err), _p(valid), C.c_int(chunk))
+        self.L.emu_glv_mul(*[_p(a) for a in arrs], _p(cols), C.c_size_t(n), C.c_size_t(n), _p(err), _p(valid), C.c_int(chunk),
+                           C.c_int(run_iters))
         return cols, err, valid
 
 

@@ -14,12 +14,14 @@
 using namespace p2e;
 
 static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx,
-                const uint8_t* pky, uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid, int chunk) {
+                const uint8_t* pky, uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid, int chunk,
+                int run_iters) {
     host::ScheduleBuilder sb;
     if (program == 0)
         sb.verify_secp256k1_message_circuit();
     else
         sb.glv_mul_circuit();
+    sb.mark_runs(run_iters);
     const Program& G = sb.prog;
     const host::Consts& C = host::consts();
     std::vector<U256> PX((size_t)G.num_slots * n), PY((size_t)G.num_slots * n), PZ((size_t)G.num_slots * n),
@@ -62,28 +64,48 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
         for (long long i = 0; i < (long long)n; i++)
             for (int t = lo; t < hi; t++) body_expand<Emit>(G, B, (size_t)i, t);
     };
-    const int pieces = 3;
+    auto expand_runs = [&](int it0, int it1) {
+        for (int a = it0; a < it1; a += run_iters) {
+            int b = a + run_iters < it1 ? a + run_iters : it1;
+#pragma omp parallel for
+            for (long long i = 0; i < (long long)n; i++) body_expand_run<Emit>(G, B, (size_t)i, a, b);
+        }
+    };
+    // the same plan as run_program() in csrc/p2e_hip.hip: fixed-base chain; window table piece (inverted
+    // before the loop, which then reads it affine); the loop cut at run boundaries into `groups` pieces whose
+    // phase C walks runs; the trailing unblinding add and the final add op by op
     if (G.num_chains == 3) {
         chain(G.chain_begin[1], G.chain_end[1], false);
         binv(G.chain_begin[1], G.chain_end[1]);
         expand(G.chain_begin[1], G.chain_end[1]);
     }
     {
-        // first piece = the 23-op window table, inverted before the loop pieces run (they then read it affine)
-        int lo = G.chain_begin[0], hi = G.chain_end[0];
-        int per = (hi - lo - 23 + pieces - 2) / (pieces - 1);
-        for (int a = lo; a < hi;) {
-            int b = a == lo ? lo + 23 : (a + per < hi ? a + per : hi);
-            chain(a, b, a != lo);
-            if (b == hi && G.num_chains == 3) {
+        const int lo0 = G.chain_begin[0], hi0 = G.chain_end[0], lb = G.msm_loop_begin, iters = G.msm_loop_iters;
+        const int le = lb + 3 * iters, R = run_iters > 0 ? run_iters : 1, groups = 3;
+        chain(lo0, lb, false);
+        binv(lo0, lb);
+        expand(lo0, lb);
+        const int nruns = (iters + R - 1) / R;
+        int rn = 0;
+        for (int g = 0; g < groups; g++) {
+            int take = (nruns - rn + (groups - g) - 1) / (groups - g);
+            int it0 = rn * R, it1 = (rn + take) * R < iters ? (rn + take) * R : iters;
+            int a = lb + 3 * it0, b = lb + 3 * it1;
+            const bool last = g == groups - 1;
+            if (last) b = hi0;
+            chain(a, b, true);
+            if (last && G.num_chains == 3) {
                 chain(G.chain_begin[2], G.chain_end[2], false, true);
-                binv(a, G.chain_end[2]);
-                expand(a, G.chain_end[2]);
+                b = G.chain_end[2];
+            }
+            binv(a, b);
+            if (run_iters > 0) {
+                expand_runs(it0, it1);
+                if (last) expand(le, b);
             } else {
-                binv(a, b);
                 expand(a, b);
             }
-            a = b;
+            rn += take;
         }
     }
     long bad = 0;
@@ -139,12 +161,12 @@ long emu_bingcd_selfcheck(int field, unsigned long long seed, size_t n) {
     return fails;
 }
 long emu_verify(const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx, const uint8_t* pky,
-                uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid, int chunk) {
-    return run(0, msg, r, s, pkx, pky, cols, n, ld, err, valid, chunk);
+                uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid, int chunk, int run_iters) {
+    return run(0, msg, r, s, pkx, pky, cols, n, ld, err, valid, chunk, run_iters);
 }
 long emu_glv_mul(const uint8_t* px, const uint8_t* py, const uint8_t* k, uint64_t* cols, size_t n, size_t ld,
-                 uint8_t* err, uint8_t* valid, int chunk) {
-    return run(1, k, k, k, px, py, cols, n, ld, err, valid, chunk);
+                 uint8_t* err, uint8_t* valid, int chunk, int run_iters) {
+    return run(1, k, k, k, px, py, cols, n, ld, err, valid, chunk, run_iters);
 }
 #define LOOP(expr)                                  \
     long bad = 0;                                   \

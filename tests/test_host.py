@@ -81,6 +81,17 @@ def test_batch_inversion_chunking_is_output_invariant(chunk):
     assert not err.any() and valid.all() and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("run_iters", [0, 1, 3, 73])
+def test_expansion_run_length_is_output_invariant(run_iters):
+    """Phase C walks MSM-loop iterations in runs (phase B skips the affine conversion inside a run): any run
+    length, and op-by-op expansion (0), must give the same columns."""
+    emu, ora = EmuBackend(), OracleBackend()
+    arrs = p2e.synth_signatures(seed=22, n=3)
+    want, _, _ = ora.verify(*arrs)
+    got, err, valid = emu.verify(*arrs, run_iters=run_iters)
+    assert not err.any() and valid.all() and np.array_equal(got, want)
+
+
 def test_pipeline_edge_inputs():
     """Inputs the reference accepts but a naive implementation gets wrong: non-canonical coordinates
     (>= p, < 2^256), a signature that does not verify, s with small inverse, pk = G."""

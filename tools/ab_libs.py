@@ -13,8 +13,13 @@ ld = n + 16
 big = torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device="cuda")
 err = torch.empty(n, dtype=torch.uint8, device="cuda"); valid = torch.empty(n, dtype=torch.uint8, device="cuda")
 ctxs = []
-for path in libs:
-    L = C.CDLL(path)
+for spec in libs:   # "path" or "path@R" (R = P2E_RUN_ITERS for that context)
+    path, _, r = spec.partition("@")
+    if r:
+        os.environ["P2E_RUN_ITERS"] = r
+    else:
+        os.environ.pop("P2E_RUN_ITERS", None)
+    L = C.CDLL(os.path.abspath(path))
     h = C.c_void_p()
     L.p2e_ecdsa_verify_witness_batch.restype = C.c_long
     assert L.p2e_ctx_create(C.c_int(0), C.c_uint(0), C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(h)) == 0
