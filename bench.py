@@ -12,11 +12,13 @@ sharded by contiguous signature ranges with no data-path collective ("scaling": 
 fixed as N grows).  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     the dominant kernel, k_expand (writes 82 067 of the 82 615 columns; launched once per
-               schedule segment, 5 launches per step by default).  achieved =
-               algorithmic bytes per launch / average launch duration, the duration measured live with
-               HIP events on the stream the kernel runs on (p2e_last_phase_ms).  traffic = HBM bytes per
-               launch from the rocprofv3 PMC summary committed under profiles/ (null if absent).
+  roofline     the dominant kernel, k_expand_runs (the MSM double/double/conditional-add loop: 59 495 of the
+               82 615 columns, one launch per schedule segment of the loop).  achieved = algorithmic bytes
+               per launch / average launch duration, the duration measured live with HIP events on the
+               stream the kernel runs on (p2e_last_phase_ms).  traffic = HBM bytes per launch from the
+               rocprofv3 PMC summary committed under profiles/ (null if absent).
+  roofline_k_expand   the same figures for k_expand (window table, fixed-base chain, trailing adds: 22 572
+               columns, one curve op per workgroup row).
   cpu_baseline oracle/libp2e_oracle.so (C restatement of the reference's CPU algorithm: affine ops, one
                Fermat inversion per inverse, OpenMP over signatures) timed on a bounded sample on the
                host cores of this box.  kind "port": the Rust reference cannot be built offline.
@@ -174,30 +176,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    expand_ms, expand_cols, expand_launches = [], 0.0, 0
+    kstat = {k: {"ms": [], "cols": 0.0, "launches": 0} for k in ("expand", "runs")}
     phase_acc = {}
+
+    def note(ph, weight=1.0):
+        for k, st in kstat.items():
+            st["ms"].append(ph[k])
+            st["cols"], st["launches"] = ph[k + "_cols"], int(ph[k + "_launches"])
+        for k in ("scalar", "expand", "runs", "total"):
+            phase_acc[k] = phase_acc.get(k, 0.0) + ph[k] * weight
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         if depth > 1:
             continue
-        ph = ctx.last_phase_ms()
-        expand_ms.append(ph["expand"])
-        expand_cols, expand_launches = ph["expand_cols"], int(ph["expand_launches"])
-        for k in ("scalar", "expand", "total"):
-            phase_acc[k] = phase_acc.get(k, 0.0) + ph[k]
+        note(ctx.last_phase_ms())
     if depth > 1:
         drain()
     barrier()
     elapsed = time.perf_counter() - t0
     if depth > 1:                              # per-launch timings of the last batch of every context
         for c in ctxs:
-            ph = c.last_phase_ms()
-            expand_ms.append(ph["expand"])
-            expand_cols, expand_launches = ph["expand_cols"], int(ph["expand_launches"])
-            for k in ("scalar", "expand", "total"):
-                phase_acc[k] = phase_acc.get(k, 0.0) + ph[k] * args.steps / depth
+            note(c.last_phase_ms(), args.steps / depth)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -219,11 +220,23 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed
-        # k_expand runs as `expand_launches` launches per step (one per schedule segment); per launch:
-        avg_expand_s = sum(expand_ms) / len(expand_ms) / 1e3 / expand_launches
-        alg_bytes = int(expand_cols) * 8 * n // expand_launches
-        achieved = alg_bytes / avg_expand_s / 1e9
-        pmc = pmc_traffic()
+        pmc = pmc_traffic() or {}
+
+        def roofline(kernel, st):
+            # `launches` launches per step (one per schedule segment); per launch:
+            if not st["launches"]:
+                return None
+            avg_s = sum(st["ms"]) / len(st["ms"]) / 1e3 / st["launches"]
+            alg_bytes = int(st["cols"]) * 8 * n // st["launches"]
+            achieved = alg_bytes / avg_s / 1e9
+            return {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                    "avg_launch_ms": round(avg_s * 1e3, 4), "launches_per_step": st["launches"],
+                    "cols_per_fill_all_launches": int(st["cols"]),
+                    "traffic": (pmc.get("hbm_bytes_per_launch") or {}).get(kernel),
+                    "traffic_source": pmc.get("source")}
+
+        runs_line, expand_line = roofline("k_expand_runs", kstat["runs"]), roofline("k_expand", kstat["expand"])
         line = {
             "metric": "secp256k1 ECDSA witness fills/sec at batch=2^16, 1/2/4/8 MI355X; bit-exact",
             "value": round(value, 1), "unit": "fills/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -239,13 +252,11 @@ def main():
                            "GBps_per_gpu": round(value * BYTES_PER_FILL / world / 1e9, 1),
                            "frac_of_hbm_peak": round(value * BYTES_PER_FILL / world / 1e9 / HBM_PEAK_GBS, 4)},
             "phase_ms_per_step": {k: round(v / args.steps, 4) for k, v in phase_acc.items()},
-            "roofline": {"kernel": "k_expand", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_expand_s * 1e3, 4),
-                         "launches_per_step": expand_launches, "cols_per_fill_all_launches": int(expand_cols),
-                         "traffic": (pmc or {}).get("hbm_bytes_per_launch_avg"),
-                         "traffic_source": (pmc or {}).get("source")},
+            # P2E_RUN_ITERS=0 expands everything op by op: k_expand is then the only expansion kernel
+            "roofline": runs_line or expand_line,
         }
+        if runs_line:
+            line["roofline_k_expand"] = expand_line
         if gather:
             line["allgather"] = gather
         if world == 1 and not args.no_cpu_baseline:

@@ -64,18 +64,22 @@ extern "C" {
 typedef struct p2e_ctx p2e_ctx;
 
 /* ---- context ------------------------------------------------------------------------------------ */
-/* `stream`: a hipStream_t to run on (e.g. torch's current stream), or NULL for a library-owned one. */
+/* `stream`: a hipStream_t to run on (e.g. torch's current stream), or NULL for a library-owned one.  The
+ * library-owned stream is a blocking stream (hipStreamDefault): work the caller queued on the legacy default
+ * stream before a call is ordered before it, and default-stream work queued after a call is ordered after it. */
 int p2e_ctx_create(int device, unsigned flags, void *stream, p2e_ctx **out);
 void p2e_ctx_destroy(p2e_ctx *ctx);
 int p2e_sync(p2e_ctx *ctx);
 const char *p2e_last_error(void);
 /* bytes of device scratch the fused entry points need for a batch of n (allocated lazily, kept) */
 size_t p2e_scratch_bytes(int program /*0 verify, 1 glv_mul*/, size_t n);
-/* Timing of the last fused call, measured with hipEvents on the context's stream:
- * out[0] = ms of the scalar kernel, out[1] = number of k_expand launches (the schedule is cut into
- * segments whose Jacobian chains run on internal streams underneath), out[2] = witness columns per
- * signature those launches wrote, out[3] = their summed durations in ms, out[4] = ms of the whole call.
- * Returns the number written. */
+/* Timing of the last fused call, measured with hipEvents on the context's stream around every launch.
+ * The schedule is cut into segments whose Jacobian chains run on internal streams underneath; each
+ * finished segment is expanded by k_expand (one curve op per workgroup row: window table, fixed-base
+ * chain, trailing adds) and/or k_expand_runs (runs of MSM-loop iterations).
+ * out[0] = ms of the scalar kernel, out[4] = ms of the whole call;
+ * out[1], out[2], out[3] = k_expand: launches, witness columns per signature they wrote, summed ms;
+ * out[5], out[6], out[7] = the same three for k_expand_runs.  Returns the number written (<= 8). */
 int p2e_last_phase_ms(p2e_ctx *ctx, float *out, int cap);
 
 /* ---- single generators (one reference run_once body each) ----------------------------------------- */
@@ -118,6 +122,34 @@ long p2e_ecdsa_verify_witness_batch(p2e_ctx *ctx, const uint8_t *msg32, const ui
 /* glv_mul(p, k) gadgets/glv.rs:87-104: cols[P2E_GLV_MUL_COLS][ld]. */
 long p2e_glv_mul_witness_batch(p2e_ctx *ctx, const uint8_t *px32, const uint8_t *py32, const uint8_t *k32,
                                uint64_t *cols, size_t n, size_t ld, uint8_t *err, uint8_t *valid);
+
+/* ---- built-in-generator columns ------------------------------------------- */
+/* The values of the targets that plonky2's OWN generators fill between the hot-path generators of the same
+ * circuit, derived on the GPU from the finished witness matrix `cols` (as written by
+ * p2e_ecdsa_verify_witness_batch for program 0 / p2e_glv_mul_witness_batch for program 1), the constant tables
+ * and the pk.y input, in the order the gadgets create the targets:
+ *   split_nonnative_to_4_bit_limbs / _2_bit_limbs  gadgets/split_nonnative.rs:25-72  split_le_base bits of every
+ *        limb, then (lower, upper, limb) per 4-bit digit / the limb per 2-bit digit
+ *   per fixed-base window  gadgets/curve_fixed_base.rs:56-61  is_equal(limb, zero), not(.), the
+ *        random_access_curve_points selection (gadgets/curve_windowed_mul.rs:74-118: 9 x limbs, 9 y limbs)
+ *   per MSM digit  gadgets/curve_msm.rs:67-71  index = mul_add(four, limb_m, limb_n), the selection, is_equal, not
+ *   per curve_conditional_add  gadgets/curve.rs:232-238  not(b), then the mul_biguint_by_bool products
+ *        (gadgets/biguint.rs:360-374) sum.x*b, sum.y*b, p1.x*not_b, p1.y*not_b
+ *   per nonnative_conditional_neg  gadgets/nonnative.rs:590-593  not(b), neg*b, x*not_b
+ * aux[P2E_VERIFY_AUX_COLS or P2E_GLV_MUL_AUX_COLS][ld_aux], column-major like cols.  err[i] gets
+ * P2E_ERR_LIMB_RANGE where a split scalar has a limb >= 2^29 (split_le_base has no witness then).  Wire
+ * placement of these targets is not part of this library (plonky2's gate sources are not available offline). */
+#define P2E_VERIFY_AUX_COLS 8959
+#define P2E_GLV_MUL_AUX_COLS 4738
+long p2e_aux_witness_batch(p2e_ctx *ctx, int program, const uint8_t *pky32, const uint64_t *cols, size_t ld,
+                           uint64_t *aux, size_t ld_aux, size_t n, uint8_t *err);
+typedef struct p2e_aux_desc {
+    int32_t kind; /* 0 split4, 1 split2, 2 fixed-base window, 3 MSM digit, 4 conditional neg */
+    uint32_t first_col, num_cols;
+    char label[48];
+} p2e_aux_desc;
+long p2e_aux_describe(int program, p2e_aux_desc *out, size_t cap);
+long p2e_aux_num_cols(int program);
 
 /* ---- layout helper --------------------------------------------------------------------------------- */
 /* cols[ncols][ld] (column-major over the batch) -> rows[n][row_ld], one contiguous witness per signature:

@@ -246,6 +246,20 @@ def main():
                         inputs=np.frombuffer(b"".join(v.to_bytes(32, "little") for s in g_in for v in s),
                                              dtype=np.uint8).reshape(len(g_in), 3, 32))
     write_gz(os.path.join(OUT, "schedule_glv_mul.json.gz"), json.dumps([list(o) for o in gops], separators=(",", ":")))
+
+    # built-in-generator values of the same golden inputs, and their column map
+    aux, aops = [], None
+    for s in sigs:
+        _c, a, _ok, aops = R.verify_witness_aux(*s)
+        aux.append(a)
+    gaux, gaops = [], None
+    for px, py, k in g_in:
+        _c, a, _ok, gaops = R.glv_mul_witness_aux(px, py, k)
+        gaux.append(a)
+    np.savez_compressed(os.path.join(OUT, "aux_golden.npz"), verify=np.array(aux, dtype=np.uint64).T.copy(),
+                        glv_mul=np.array(gaux, dtype=np.uint64).T.copy())
+    write_gz(os.path.join(OUT, "aux_schedule.json.gz"),
+             json.dumps({"verify": [list(o) for o in aops], "glv_mul": [list(o) for o in gaops]}, separators=(",", ":")))
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -16,6 +16,8 @@ _LIB = None
 
 VERIFY_COLS = 82615
 GLV_MUL_COLS = 65243
+VERIFY_AUX = 8959
+GLV_MUL_AUX = 4738
 
 
 def build():
@@ -31,7 +33,7 @@ def lib():
         _LIB = C.CDLL(path)
         for name in ("mul_witness", "checksum_witness", "add_witness", "sub_witness", "add_many_witness",
                      "inv_witness", "glv_decompose", "limb_split", "limb_pack", "verify_witness",
-                     "glv_mul_witness"):
+                     "glv_mul_witness", "verify_witness_aux", "glv_mul_witness_aux"):
             getattr(_LIB, "p2e_oracle_" + name).restype = C.c_long
     return _LIB
 
@@ -153,6 +155,29 @@ def glv_mul_witness(px, py, k, nthreads=0):
     lib().p2e_oracle_glv_mul_witness(*[_p(a) for a in arrs], _p(cols), C.c_size_t(n), C.c_size_t(n), _p(err),
                                      _p(flags), C.c_int(nthreads))
     return cols, err, flags
+
+
+def verify_witness_aux(msg, r, s, pkx, pky, nthreads=0):
+    """(cols, aux, err, flags): hot-path columns plus the built-in-generator values (p2e_oracle.h)."""
+    arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (msg, r, s, pkx, pky)]
+    n = arrs[0].shape[0]
+    cols, aux = _cols(VERIFY_COLS, n), _cols(VERIFY_AUX, n)
+    err = np.zeros(n, dtype=np.uint8)
+    flags = np.zeros(n, dtype=np.uint8)
+    lib().p2e_oracle_verify_witness_aux(*[_p(a) for a in arrs], _p(cols), C.c_size_t(n), C.c_size_t(n), _p(aux),
+                                        C.c_size_t(n), _p(err), _p(flags), C.c_int(nthreads))
+    return cols, aux, err, flags
+
+
+def glv_mul_witness_aux(px, py, k, nthreads=0):
+    arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (px, py, k)]
+    n = arrs[0].shape[0]
+    cols, aux = _cols(GLV_MUL_COLS, n), _cols(GLV_MUL_AUX, n)
+    err = np.zeros(n, dtype=np.uint8)
+    flags = np.zeros(n, dtype=np.uint8)
+    lib().p2e_oracle_glv_mul_witness_aux(*[_p(a) for a in arrs], _p(cols), C.c_size_t(n), C.c_size_t(n), _p(aux),
+                                         C.c_size_t(n), _p(err), _p(flags), C.c_int(nthreads))
+    return cols, aux, err, flags
 
 
 def rando():

@@ -572,7 +572,28 @@ typedef struct {
     u64 *out;
     size_t ld, idx, col;
     uint8_t err;
+    /* values of the targets plonky2's built-in generators fill on the same path (bool
+     * selects, window bits / digits, random-access selections, is_equal / not results) in gadget creation order;
+     * a separate column matrix, NULL = not wanted */
+    u64 *aux;
+    size_t ald, acol;
 } walker;
+
+static void aux_emit(walker *w, const u64 *v, int n) {
+    if (!w->aux) return;
+    for (int i = 0; i < n; i++) w->aux[(w->acol + (size_t)i) * w->ald + w->idx] = v[i];
+    w->acol += (size_t)n;
+}
+static u64 w_not(walker *w, u64 b) { /* builder.not(b) = 1 - b */
+    u64 v = 1 - b;
+    aux_emit(w, &v, 1);
+    return v;
+}
+static u64 w_is_zero(walker *w, u64 x) { /* builder.is_equal(x, zero) */
+    u64 v = x == 0;
+    aux_emit(w, &v, 1);
+    return v;
+}
 
 static void emit(walker *w, const u64 *v, int n) {
     for (int i = 0; i < n; i++) w->out[(w->col + (size_t)i) * w->ld + w->idx] = v[i];
@@ -623,15 +644,18 @@ static nn nn_from(const u64 *l) {
     memcpy(z.l, l, sizeof z.l);
     return z;
 }
-static nn nn_mul_bool(const nn *a, u64 b) { /* gadgets/biguint.rs:360-374 */
+/* gadgets/biguint.rs:360-374: one builder.mul per limb of `a`; nl = number of limbs the target really has */
+static nn w_mul_bool(walker *w, const nn *a, int nl, u64 b) {
     nn r;
     for (int i = 0; i < NL; i++) r.l[i] = gl_mul(a->l[i], b);
+    aux_emit(w, r.l, nl);
     return r;
 }
-static nn w_cond_neg(walker *w, const nn *x, u64 b, int field) { /* gadgets/nonnative.rs:584-596 */
+static nn w_cond_neg(walker *w, const nn *x, int nl, u64 b, int field) { /* gadgets/nonnative.rs:584-596 */
+    u64 not_b = w_not(w, b);
     nn z = nn_zero();
     nn neg = w_sub(w, &z, x, field);
-    nn t = nn_mul_bool(&neg, b), f = nn_mul_bool(x, 1 - b);
+    nn t = w_mul_bool(w, &neg, NL, b), f = w_mul_bool(w, x, nl, not_b);
     return w_add(w, &t, &f, field);
 }
 static pt w_curve_add(walker *w, const pt *p1, const pt *p2) { /* gadgets/curve.rs:202-223 */
@@ -675,10 +699,14 @@ static pt w_curve_double(walker *w, const pt *p) { /* gadgets/curve.rs:160-185 *
     r.y = w_sub(w, &lx, &p->y, F);
     return r;
 }
-static pt w_curve_cond_add(walker *w, const pt *p1, const pt *p2, u64 b) { /* gadgets/curve.rs:225-243 */
+/* gadgets/curve.rs:225-243; nlx, nly = limb counts of p1 (a constant point may have fewer than 9) */
+static pt w_curve_cond_add(walker *w, const pt *p1, int nlx, int nly, const pt *p2, u64 b) {
+    u64 not_b = w_not(w, b);
     pt s = w_curve_add(w, p1, p2);
-    nn xt = nn_mul_bool(&s.x, b), xf = nn_mul_bool(&p1->x, 1 - b);
-    nn yt = nn_mul_bool(&s.y, b), yf = nn_mul_bool(&p1->y, 1 - b);
+    nn xt = w_mul_bool(w, &s.x, NL, b);
+    nn yt = w_mul_bool(w, &s.y, NL, b);
+    nn xf = w_mul_bool(w, &p1->x, nlx, not_b);
+    nn yf = w_mul_bool(w, &p1->y, nly, not_b);
     pt r;
     r.x = w_add(w, &xt, &xf, P2E_O_FIELD_BASE);
     r.y = w_add(w, &yt, &yf, P2E_O_FIELD_BASE);
@@ -701,12 +729,42 @@ static unsigned digit_of(const u64 *limbs, int nl, int wbits, int t) {
     }
     return d;
 }
+/* split_le_base::<2>(limb, 29) of every limb (gadgets/split_nonnative.rs:33,60) */
+static void aux_bits(walker *w, const u64 *limbs, int nl) {
+    for (int i = 0; i < nl; i++)
+        for (int k = 0; k < BITS; k++) {
+            u64 b = (limbs[i] >> k) & 1;
+            aux_emit(w, &b, 1);
+        }
+}
+/* random_access_curve_points gadgets/curve_windowed_mul.rs:74-118: selected x limbs, then selected y limbs */
+static void aux_point(walker *w, const pt *p) {
+    aux_emit(w, p->x.l, NL);
+    aux_emit(w, p->y.l, NL);
+}
+/* limbs constant_biguint gives a constant (convert_base gadgets/biguint.rs:27-51: no zero limbs on top) */
+static int const_nlimbs(const u64 *l) {
+    int n = NL;
+    while (n > 0 && l[n - 1] == 0) n--;
+    return n;
+}
 static pt w_fixed_base(walker *w, const nn *scalar) { /* gadgets/curve_fixed_base.rs:18-66 */
     pt result = pt_from(RANDO_L);
+    int nlx = const_nlimbs(RANDO_L[0]), nly = const_nlimbs(RANDO_L[1]);
+    /* split_nonnative_to_4_bit_limbs gadgets/split_nonnative.rs:25-50 */
+    aux_bits(w, scalar->l, NL);
+    for (int i = 0; i < FB_WINDOWS; i++) {
+        u64 d = digit_of(scalar->l, NL, 4, i);
+        u64 c[3] = {d & 3, d >> 2, d}; /* lower, upper, combined limb */
+        aux_emit(w, c, 3);
+    }
     for (int i = 0; i < FB_WINDOWS; i++) {
         unsigned d = digit_of(scalar->l, NL, 4, i);
+        u64 should_add = w_not(w, w_is_zero(w, d));
         pt r = pt_from(FB_TABLE[i][d]);
-        result = w_curve_cond_add(w, &result, &r, d != 0);
+        aux_point(w, &r);
+        result = w_curve_cond_add(w, &result, nlx, nly, &r, should_add);
+        nlx = nly = NL;
     }
     pt nr = pt_from(NEG_RANDO_L);
     return w_curve_add(w, &result, &nr);
@@ -714,6 +772,15 @@ static pt w_fixed_base(walker *w, const nn *scalar) { /* gadgets/curve_fixed_bas
 static pt w_msm(walker *w, const pt *p, const pt *q, const u64 *n5, const u64 *m5) { /* gadgets/curve_msm.rs:21-79 */
     pt pre[16];
     pt rando = pt_from(RANDO_L), nr = pt_from(NEG_RANDO_L);
+    /* split_nonnative_to_2_bit_limbs(n), then (m): gadgets/split_nonnative.rs:52-72 */
+    for (int which = 0; which < 2; which++) {
+        const u64 *l5 = which ? m5 : n5;
+        aux_bits(w, l5, 5);
+        for (int t = 0; t < 73; t++) {
+            u64 dg = digit_of(l5, 5, 2, t);
+            aux_emit(w, &dg, 1);
+        }
+    }
     for (int i = 0; i < 16; i++) pre[i] = *p;
     pt cur_p = rando, cur_q = rando;
     for (int i = 0; i < 4; i++) {
@@ -732,8 +799,11 @@ static pt w_msm(walker *w, const pt *p, const pt *q, const u64 *n5, const u64 *m
     for (int d = 72; d >= 0; d--) { /* 5 limbs -> 145 bits -> 146 -> 73 digits, MSB first */
         result = w_curve_double(w, &result);
         result = w_curve_double(w, &result);
-        unsigned idx = 4 * digit_of(m5, 5, 2, d) + digit_of(n5, 5, 2, d);
-        result = w_curve_cond_add(w, &result, &pre[idx], idx != 0);
+        u64 idx = 4 * digit_of(m5, 5, 2, d) + digit_of(n5, 5, 2, d); /* mul_add(four, limb_m, limb_n) */
+        aux_emit(w, &idx, 1);
+        aux_point(w, &pre[idx]);
+        u64 should_add = w_not(w, w_is_zero(w, idx));
+        result = w_curve_cond_add(w, &result, NL, NL, &pre[idx], should_add);
     }
     pt to_add = pt_from(NEG_RANDO_146_L);
     return w_curve_add(w, &result, &to_add);
@@ -748,8 +818,8 @@ static pt w_glv_mul(walker *w, const pt *p, const nn *k, int *ok) { /* gadgets/g
     emit(w, k2.l, 5);
     emit(w, &n1, 1);
     emit(w, &n2, 1);
-    nn k1r = w_cond_neg(w, &k1, n1, S);
-    nn k2r = w_cond_neg(w, &k2, n2, S);
+    nn k1r = w_cond_neg(w, &k1, 5, n1, S);
+    nn k2r = w_cond_neg(w, &k2, 5, n2, S);
     nn gs = nn_from(GLV_S_L);
     nn sb = w_mul(w, &gs, &k2r, S);
     sb = w_add(w, &sb, &k1r, S);
@@ -760,9 +830,9 @@ static pt w_glv_mul(walker *w, const pt *p, const nn *k, int *ok) { /* gadgets/g
     sp.y = p->y;
     pt pn, spn;
     pn.x = p->x;
-    pn.y = w_cond_neg(w, &p->y, n1, P2E_O_FIELD_BASE);
+    pn.y = w_cond_neg(w, &p->y, NL, n1, P2E_O_FIELD_BASE);
     spn.x = sp.x;
-    spn.y = w_cond_neg(w, &sp.y, n2, P2E_O_FIELD_BASE);
+    spn.y = w_cond_neg(w, &sp.y, NL, n2, P2E_O_FIELD_BASE);
     return w_msm(w, &pn, &spn, k1.l, k2.l);
 }
 static nn nn_from_bytes(const uint8_t *b) {
@@ -964,6 +1034,11 @@ long p2e_oracle_limb_pack(const uint64_t *limbs, uint8_t *packed, size_t n, size
 long p2e_oracle_verify_witness(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
                                const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint8_t *err,
                                uint8_t *flags, int nthreads) {
+    return p2e_oracle_verify_witness_aux(msg, r, s, pkx, pky, cols, n, ld, NULL, 0, err, flags, nthreads);
+}
+long p2e_oracle_verify_witness_aux(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
+                                   const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint64_t *aux,
+                                   size_t ald, uint8_t *err, uint8_t *flags, int nthreads) {
     oracle_init();
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -972,7 +1047,7 @@ long p2e_oracle_verify_witness(const uint8_t *msg, const uint8_t *r, const uint8
 #endif
 #pragma omp parallel for schedule(dynamic, 1)
     for (size_t i = 0; i < n; i++) {
-        walker w = {cols, ld, i, 0, 0};
+        walker w = {cols, ld, i, 0, 0, aux, ald, 0};
         uint8_t f = 0;
         walk_verify(&w, msg + 32 * i, r + 32 * i, s + 32 * i, pkx + 32 * i, pky + 32 * i, &f);
         err[i] = w.err;
@@ -982,6 +1057,11 @@ long p2e_oracle_verify_witness(const uint8_t *msg, const uint8_t *r, const uint8
 }
 long p2e_oracle_glv_mul_witness(const uint8_t *px, const uint8_t *py, const uint8_t *k, uint64_t *cols,
                                 size_t n, size_t ld, uint8_t *err, uint8_t *flags, int nthreads) {
+    return p2e_oracle_glv_mul_witness_aux(px, py, k, cols, n, ld, NULL, 0, err, flags, nthreads);
+}
+long p2e_oracle_glv_mul_witness_aux(const uint8_t *px, const uint8_t *py, const uint8_t *k, uint64_t *cols,
+                                    size_t n, size_t ld, uint64_t *aux, size_t ald, uint8_t *err, uint8_t *flags,
+                                    int nthreads) {
     oracle_init();
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -990,7 +1070,7 @@ long p2e_oracle_glv_mul_witness(const uint8_t *px, const uint8_t *py, const uint
 #endif
 #pragma omp parallel for schedule(dynamic, 1)
     for (size_t i = 0; i < n; i++) {
-        walker w = {cols, ld, i, 0, 0};
+        walker w = {cols, ld, i, 0, 0, aux, ald, 0};
         pt p;
         p.x = nn_from_bytes(px + 32 * i);
         p.y = nn_from_bytes(py + 32 * i);

@@ -32,6 +32,8 @@ extern "C" {
 
 #define P2E_O_VERIFY_COLS 82615
 #define P2E_O_GLV_MUL_COLS 65243
+#define P2E_O_VERIFY_AUX 8959
+#define P2E_O_GLV_MUL_AUX 4738
 
 /* each returns the number of elements with err != 0 */
 /* gates/mul_nonnative.rs:249-324 + :513-531 : x[9][n], y[9][n] -> r[9], q[9], cs[17], b[16] */
@@ -67,6 +69,20 @@ long p2e_oracle_verify_witness(const uint8_t *msg, const uint8_t *r, const uint8
 /* gadgets/glv.rs:87-104 : cols[65243][n] */
 long p2e_oracle_glv_mul_witness(const uint8_t *px, const uint8_t *py, const uint8_t *k, uint64_t *cols,
                                 size_t n, size_t ld, uint8_t *err, uint8_t *flags, int nthreads);
+
+/* The same walks, additionally recording aux[8959][n] / aux[4738][n]: the values of the targets that plonky2's
+ * BUILT-IN generators fill on this path, in the order the gadgets create them:
+ * split_le_base bits and the 4-/2-bit digits built from them (gadgets/split_nonnative.rs:25-72), is_equal / not
+ * results and the random_access_curve_points selection per window (gadgets/curve_fixed_base.rs:56-61,
+ * gadgets/curve_msm.rs:67-71, gadgets/curve_windowed_mul.rs:74-118), not(b) and the mul_biguint_by_bool products
+ * of every conditional add / negation (gadgets/curve.rs:225-243, gadgets/nonnative.rs:584-596,
+ * gadgets/biguint.rs:360-374).  aux == NULL: not recorded. */
+long p2e_oracle_verify_witness_aux(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
+                                   const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint64_t *aux,
+                                   size_t ald, uint8_t *err, uint8_t *flags, int nthreads);
+long p2e_oracle_glv_mul_witness_aux(const uint8_t *px, const uint8_t *py, const uint8_t *k, uint64_t *cols,
+                                    size_t n, size_t ld, uint64_t *aux, size_t ald, uint8_t *err, uint8_t *flags,
+                                    int nthreads);
 
 /* constants computed at init (for tests): rando = keccak256(0u64 LE) as LE scalar * G */
 void p2e_oracle_rando(uint8_t x32[32], uint8_t y32[32]);

@@ -420,11 +420,30 @@ class Walker:
         self.cols = []
         self.ops = []
         self._path = []
+        # values of the targets that plonky2's BUILT-IN generators fill on the same
+        # path (bool selects, window bits/digits, random-access selections, is_equal / not results), in the
+        # order the gadgets create them.  Separate vector: the hot-path columns above are unchanged.
+        self.aux = []
+        self.aux_ops = []
 
     # -- bookkeeping
     def _rec(self, kind, field, vals):
         self.ops.append((kind, field, len(self.cols), len(vals), "/".join(self._path)))
         self.cols.extend(int(v) for v in vals)
+
+    def _aux(self, kind, vals):
+        self.aux_ops.append((kind, len(self.aux), len(vals), "/".join(self._path)))
+        self.aux.extend(int(v) for v in vals)
+
+    def not_(self, b):                                          # plonky2 builder.not: 1 - b
+        v = 1 - b
+        self._aux("not", [v])
+        return v
+
+    def is_equal_zero(self, x):                                 # builder.is_equal(x, zero) result
+        v = int(x == 0)
+        self._aux("is_zero", [v])
+        return v
 
     class _Scope:
         def __init__(self, w, name):
@@ -475,14 +494,16 @@ class Walker:
     def neg_nonnative(self, x, field):                          # :491-500 (zero constant has 0 limbs)
         return self.sub_nonnative(const_limbs(0), x, field)
 
-    @staticmethod
-    def mul_by_bool(a, b):                                      # gadgets/biguint.rs:360-374
-        return [gl(l * b) for l in a]
+    def mul_by_bool(self, a, b):                                # gadgets/biguint.rs:360-374: one mul per limb
+        v = [gl(l * b) for l in a]
+        self._aux("mul_by_bool", v)
+        return v
 
     def nonnative_conditional_neg(self, x, b, field):           # :584-596
+        not_b = self.not_(b)
         neg = self.neg_nonnative(x, field)
         t = self.mul_by_bool(neg, b)
-        f = self.mul_by_bool(x, 1 - b)
+        f = self.mul_by_bool(x, not_b)
         return self.add_nonnative(t, f, field)
 
     # -- gadgets/curve.rs
@@ -538,9 +559,14 @@ class Walker:
         return x3, y3
 
     def curve_conditional_add(self, p1, p2, b):                 # :225-243 (Q7: add always computed)
+        not_b = self.not_(b)
         s = self.curve_add(p1, p2)
-        x = self.add_nonnative(self.mul_by_bool(s[0], b), self.mul_by_bool(p1[0], 1 - b), FIELD_BASE)
-        y = self.add_nonnative(self.mul_by_bool(s[1], b), self.mul_by_bool(p1[1], 1 - b), FIELD_BASE)
+        xt = self.mul_by_bool(s[0], b)
+        yt = self.mul_by_bool(s[1], b)
+        xf = self.mul_by_bool(p1[0], not_b)
+        yf = self.mul_by_bool(p1[1], not_b)
+        x = self.add_nonnative(xt, xf, FIELD_BASE)
+        y = self.add_nonnative(yt, yf, FIELD_BASE)
         return x, y
 
     # -- gadgets/split_nonnative.rs:25-72 (bits of each 29-bit limb, LE, limb-major, zero padded)
@@ -553,24 +579,35 @@ class Walker:
             bits.extend((l >> i) & 1 for i in range(BITS))
         return bits
 
-    @classmethod
-    def split_4(cls, limbs):
-        bits = cls._bits(limbs)
+    def split_4(self, limbs):                                   # :25-50
+        bits = self._bits(limbs)
+        self._aux("bits", bits)                                 # split_le_base::<2>(limb, 29) per limb
         while len(bits) % 4:
-            bits.append(0)
-        return [bits[i] + 2 * bits[i + 1] + 4 * (bits[i + 2] + 2 * bits[i + 3]) for i in range(0, len(bits), 4)]
+            bits.append(0)                                      # builder.zero(): a constant, not a witness value
+        out, comb = [], []
+        for i in range(0, len(bits), 4):
+            lower = bits[i] + 2 * bits[i + 1]                   # mul_add(b, two, a)
+            upper = bits[i + 2] + 2 * bits[i + 3]               # mul_add(d, two, c)
+            limb = lower + 4 * upper                            # mul_add(upper, four, lower)
+            comb += [lower, upper, limb]
+            out.append(limb)
+        self._aux("comb4", comb)
+        return out
 
-    @classmethod
-    def split_2(cls, limbs):
-        bits = cls._bits(limbs)
+    def split_2(self, limbs):                                   # :52-72
+        bits = self._bits(limbs)
+        self._aux("bits", bits)
         while len(bits) % 2:
             bits.append(0)
-        return [bits[i] + 2 * bits[i + 1] for i in range(0, len(bits), 2)]
+        out = [bits[i] + 2 * bits[i + 1] for i in range(0, len(bits), 2)]
+        self._aux("comb2", out)
+        return out
 
-    @staticmethod
-    def random_access_point(idx, table):                        # gadgets/curve_windowed_mul.rs:74-118
+    def random_access_point(self, idx, table):                  # gadgets/curve_windowed_mul.rs:74-118
         x, y = table[idx]
-        return list(x) + [0] * (NL - len(x)), list(y) + [0] * (NL - len(y))
+        x, y = list(x) + [0] * (NL - len(x)), list(y) + [0] * (NL - len(y))
+        self._aux("random_access", x + y)                       # selected x limbs, then selected y limbs
+        return x, y
 
     # -- gadgets/curve_fixed_base.rs:18-66
     def fixed_base_curve_mul(self, base, scalar):
@@ -585,8 +622,9 @@ class Walker:
             with self.scope(f"win{i}"):
                 muls = fixed_base_window(point)                 # t*P_i, t=1..15 ; slot 0 := slot 1 (Q8')
                 tbl = [const_point(muls[0])] + [const_point(q) for q in muls]
+                should_add = self.not_(self.is_equal_zero(limb))
                 r = self.random_access_point(limb, tbl)
-                result = self.curve_conditional_add(result, r, int(limb != 0))
+                result = self.curve_conditional_add(result, r, should_add)
             for _ in range(4):
                 point = ec_double(point)
         with self.scope("unblind"):
@@ -619,9 +657,11 @@ class Walker:
         for d in reversed(range(num)):                          # Q9: MSB first
             with self.scope(f"digit{d}"):
                 result = self.curve_repeated_double(result, 2)
-                idx = 4 * limbs_m[d] + limbs_n[d]
+                idx = 4 * limbs_m[d] + limbs_n[d]               # mul_add(four, limb_m, limb_n)
+                self._aux("index", [idx])
                 r = self.random_access_point(idx, pre)
-                result = self.curve_conditional_add(result, r, int(idx != 0))
+                should_add = self.not_(self.is_equal_zero(idx))
+                result = self.curve_conditional_add(result, r, should_add)
         spm = rando
         for _ in range(2 * num):
             spm = ec_double(spm)
@@ -695,6 +735,8 @@ def fixed_base_window(point):
 # convenience entry points
 # ----------------------------------------------------------------------------------------------
 NUM_VERIFY_COLS = 82615
+NUM_VERIFY_AUX = 8959      # 459 (4-bit split) + 66*57 (fixed-base windows) + 30 + 38 + 436 + 73*58 (glv_mul)
+NUM_GLV_MUL_AUX = 4738     # the glv_mul part alone
 
 
 def verify_witness(msg, r, s, pkx, pky):
@@ -706,10 +748,26 @@ def verify_witness(msg, r, s, pkx, pky):
     return w.cols, ok, w.ops
 
 
+def verify_witness_aux(msg, r, s, pkx, pky):
+    """(cols, aux, ok, aux_ops): the hot-path columns plus the built-in-generator values (Walker.aux)."""
+    w = Walker()
+    ok = w.verify_secp256k1_message(limbs_of(msg, NL), limbs_of(r, NL), limbs_of(s, NL),
+                                    (limbs_of(pkx, NL), limbs_of(pky, NL)))
+    assert len(w.aux) == NUM_VERIFY_AUX, len(w.aux)
+    return w.cols, w.aux, ok, w.aux_ops
+
+
 def glv_mul_witness(pkx, pky, k):
     w = Walker()
     (_pt, ok) = w.glv_mul((limbs_of(pkx, NL), limbs_of(pky, NL)), limbs_of(k, NL))
     return w.cols, ok, w.ops
+
+
+def glv_mul_witness_aux(pkx, pky, k):
+    w = Walker()
+    (_pt, ok) = w.glv_mul((limbs_of(pkx, NL), limbs_of(pky, NL)), limbs_of(k, NL))
+    assert len(w.aux) == NUM_GLV_MUL_AUX, len(w.aux)
+    return w.cols, w.aux, ok, w.aux_ops
 
 
 # deterministic synthetic inputs (splitmix64), restating curve/ecdsa.rs:25-40 sign_message

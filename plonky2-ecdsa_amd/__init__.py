@@ -36,6 +36,8 @@ ERR_LIMB_RANGE, ERR_VALUE_GE_2_256, ERR_INVERSE_OF_ZERO, ERR_CARRY_RANGE, ERR_QU
 CTX_HOST_POINTERS, CTX_ASYNC = 1, 2
 VERIFY_COLS = 82615
 GLV_MUL_COLS = 65243
+VERIFY_AUX_COLS = 8959      # built-in-generator columns (include/p2e.h p2e_aux_witness_batch)
+GLV_MUL_AUX_COLS = 4738
 PROGRAM_VERIFY, PROGRAM_GLV_MUL = 0, 1
 
 # every symbol include/p2e.h declares
@@ -45,7 +47,7 @@ EXPORTS = (
     "p2e_add_many_witness_batch", "p2e_inv_witness_batch", "p2e_glv_decompose_batch", "p2e_limb_split",
     "p2e_limb_pack", "p2e_ecdsa_verify_witness_batch", "p2e_glv_mul_witness_batch", "p2e_columns_to_rows",
     "p2e_schedule_describe",
-    "p2e_schedule_num_cols", "p2e_synth_signatures",
+    "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
 )
 
 
@@ -98,7 +100,7 @@ def lib():
         _lib.p2e_scratch_bytes.argtypes = [C.c_int, C.c_size_t]
         for name in EXPORTS:
             if name.endswith("_batch") or name in ("p2e_limb_split", "p2e_limb_pack", "p2e_columns_to_rows", "p2e_schedule_describe",
-                                                   "p2e_schedule_num_cols"):
+                                                   "p2e_schedule_num_cols", "p2e_aux_describe", "p2e_aux_num_cols"):
                 getattr(_lib, name).restype = C.c_long
     return _lib
 
@@ -124,6 +126,24 @@ def schedule_describe(program: int = PROGRAM_VERIFY):
 
 def schedule_num_cols(program: int = PROGRAM_VERIFY) -> int:
     return int(lib().p2e_schedule_num_cols(C.c_int(program)))
+
+
+class _AuxDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("first_col", C.c_uint32), ("num_cols", C.c_uint32), ("label", C.c_char * 48)]
+
+
+def aux_describe(program: int = PROGRAM_VERIFY):
+    """Column map of the built-in-generator columns: (kind, first_col, num_cols, label) in gadget order."""
+    L = lib()
+    n = L.p2e_aux_describe(C.c_int(program), None, C.c_size_t(0))
+    arr = (_AuxDesc * n)()
+    L.p2e_aux_describe(C.c_int(program), arr, C.c_size_t(n))
+    kinds = ("split4", "split2", "fixed_base_window", "msm_digit", "conditional_neg")
+    return [(kinds[d.kind], d.first_col, d.num_cols, d.label.decode()) for d in arr]
+
+
+def aux_num_cols(program: int = PROGRAM_VERIFY) -> int:
+    return int(lib().p2e_aux_num_cols(C.c_int(program)))
 
 
 def synth_signatures(seed: int, n: int, first: int = 0):
@@ -173,9 +193,11 @@ class Context:
         return self._check(self._L.p2e_sync(self._h))
 
     def last_phase_ms(self):
-        buf = (C.c_float * 5)()
-        self._L.p2e_last_phase_ms(self._h, buf, C.c_int(5))
-        return dict(zip(("scalar", "expand_launches", "expand_cols", "expand", "total"), [float(x) for x in buf]))
+        """include/p2e.h p2e_last_phase_ms: `expand*` = k_expand launches, `runs*` = k_expand_runs launches."""
+        buf = (C.c_float * 8)()
+        self._L.p2e_last_phase_ms(self._h, buf, C.c_int(8))
+        return dict(zip(("scalar", "expand_launches", "expand_cols", "expand", "total", "runs_launches", "runs_cols",
+                         "runs"), [float(x) for x in buf]))
 
     # ---- allocation helpers -------------------------------------------------------------------------
     def _cols(self, k, n):
@@ -299,6 +321,19 @@ class Context:
         bad = self._check(self._L.p2e_ecdsa_verify_witness_batch(self._h, _ptr(msg), _ptr(r), _ptr(s), _ptr(pkx), _ptr(pky),
                                                                  _ptr(cols), C.c_size_t(n), C.c_size_t(ld), _ptr(err), _ptr(valid)))
         return cols, err, valid, bad
+
+    def aux_witness_batch(self, program, pky, cols, n=None, ld=None, aux=None, err=None, ld_aux=None):
+        """Built-in-generator columns (bool selects, window bits / digits, random-access selections, is_equal / not
+        results: SURVEY.md 8(f) rank 1) derived from a finished witness matrix: (8959 | 4738, n) columns."""
+        n = n if n is not None else self._shape(pky)[0]
+        ld = ld if ld is not None else self._shape(cols)[1]
+        if aux is None:
+            aux = self._cols(VERIFY_AUX_COLS if program == PROGRAM_VERIFY else GLV_MUL_AUX_COLS, n)
+        ld_aux = ld_aux if ld_aux is not None else self._shape(aux)[1]
+        err = err if err is not None else self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_aux_witness_batch(self._h, C.c_int(program), _ptr(pky), _ptr(cols), C.c_size_t(ld),
+                                                        _ptr(aux), C.c_size_t(ld_aux), C.c_size_t(n), _ptr(err)))
+        return aux, err, bad
 
     def glv_mul_witness_batch(self, px, py, k, cols=None, err=None, valid=None, ld=None):
         """glv_mul (gadgets/glv.rs:87-104): (65243, n) Goldilocks columns."""

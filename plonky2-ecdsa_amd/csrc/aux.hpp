@@ -1,0 +1,177 @@
+// Built-in-generator columns: the values of the targets that plonky2's OWN generators
+// fill on the ECDSA path, i.e. everything between the hot-path generators that is not a constant or an input:
+//   split_le_base bits of a scalar's limbs + the 4-/2-bit digits built from them   gadgets/split_nonnative.rs:25-72
+//   is_equal(digit, zero), not(.), the random_access_curve_points selection        gadgets/curve_fixed_base.rs:56-61,
+//                                                                                  gadgets/curve_msm.rs:67-71,
+//                                                                                  gadgets/curve_windowed_mul.rs:74-118
+//   not(b) and the four mul_biguint_by_bool products of curve_conditional_add      gadgets/curve.rs:225-243,
+//                                                                                  gadgets/biguint.rs:360-374
+//   not(b) and the two products of nonnative_conditional_neg                       gadgets/nonnative.rs:584-596
+// They are emitted in the order the gadgets create them, as a second column-major matrix aux[col * ld + sig]
+// (8 959 columns per verify, 4 738 per glv_mul).  Every value is a function of the hot-path columns, the
+// constant tables and the caller's pk.y, so this is a streaming pass over the finished witness matrix: one
+// (signature, item) per lane, coalesced column loads and stores, HBM-bound.  Wire placement of these targets
+// (BaseSumGate / RandomAccessGate / ArithmeticGate rows) is the host's business: the plonky2 sources that fix it
+// are not in the container.
+#pragma once
+#include "pipeline.hpp"
+
+namespace p2e {
+
+// where the limbs of a target live
+constexpr u32 AUX_SRC_NONE = 0xFFFFFFFFu;
+constexpr u32 AUX_SRC_CONST = 0x80000000u;     // | 2 * constant point id + (0: x, 1: y)
+constexpr u32 AUX_SRC_INPUT_PY = 0x40000000u;  // the caller's pk.y (packed 32-byte input)
+// columns of the result limbs inside the column block of one curve op (gadgets/curve.rs:160-243 emission order)
+constexpr u32 COL_ADD_X3 = 150, COL_ADD_Y3 = 221, COL_DBL_X3 = 201, COL_DBL_Y3 = 272, COL_CADD_X = 231, COL_CADD_Y = 241;
+
+enum AuxKind : uint8_t { AUX_SPLIT4 = 0, AUX_SPLIT2 = 1, AUX_FBWIN = 2, AUX_MSMDIG = 3, AUX_CNEG = 4 };
+
+struct AuxItem {
+    uint8_t kind;      // AuxKind
+    uint8_t nlx, nly;  // limbs of p1.x / p1.y (window items), of x (AUX_CNEG), of the scalar (splits)
+    uint8_t pad;
+    u32 aux_col, ncols;  // this item's aux columns
+    u32 a, b, c;         // splits: a = scalar limb column.  windows: a (and c) = digit scalars' limb columns,
+                         // b = window / digit index.  AUX_CNEG: a = column of the bool
+    u32 sumx, sumy;      // windows: limb columns of curve_add's result; AUX_CNEG: sumx = limb column of neg
+    u32 p1x, p1y;        // limbs of p1 (AUX_CNEG: p1x = limbs of x): column or AUX_SRC_* code
+};
+struct AuxTables {
+    u32 tabx[16], taby[16];  // curve_msm_circuit's precomputation[i]: limb columns (or AUX_SRC_CONST)
+    u32 num_aux_cols;
+};
+struct AuxArgs {
+    const u64* cols;  // finished witness matrix
+    size_t ld;
+    u64* aux;
+    size_t ald, n;
+    const uint8_t* py;  // pk.y, packed
+    const Aff* cpts;
+    const Aff* fbtab;
+    const AuxItem* items;
+    const AuxTables* tab;
+    u32* err;
+};
+
+P2E_HD u64 aux_col(const AuxArgs& A, u32 c, size_t i) { return A.cols[(size_t)c * A.ld + i]; }
+P2E_HD void aux_limbs_of(const U256& v, u64* l) {
+    u32 s[NL];
+    split29(v, s);
+    P2E_UNROLL
+    for (int k = 0; k < NL; k++) l[k] = s[k];
+}
+// the (zero padded) 9 limbs of a target
+P2E_HD void aux_load_limbs(const AuxArgs& A, u32 src, size_t i, u64* l, int nl) {
+    if (src & AUX_SRC_CONST) {
+        const u32 id = src & 0xFFFFu;
+        const Aff a = A.cpts[id >> 1];
+        aux_limbs_of((id & 1) ? a.y : a.x, l);
+    } else if (src == AUX_SRC_INPUT_PY) {
+        const u32* p = reinterpret_cast<const u32*>(A.py + 32 * i);
+        U256 v;
+        P2E_UNROLL
+        for (int k = 0; k < 8; k++) v.w[k] = p[k];
+        aux_limbs_of(v, l);
+    } else {
+        P2E_UNROLL
+        for (int k = 0; k < NL; k++) l[k] = k < nl ? aux_col(A, src + (u32)k, i) : 0;
+    }
+}
+// digit t (WB bits) of a scalar given as nl limb columns: bits of each 29-bit limb little-endian, limb-major,
+// zero padded (gadgets/split_nonnative.rs:33-38,60-65); a digit may straddle two limbs
+template <int WB>
+P2E_HD u32 aux_digit(const AuxArgs& A, u32 col, int nl, int t, size_t i) {
+    const int bit = WB * t, li = bit / BITS, sh = bit % BITS;
+    u64 lo = li < nl ? aux_col(A, col + (u32)li, i) : 0;
+    u32 d = (u32)(lo >> sh);
+    if (sh + WB > BITS) {
+        u64 hi = li + 1 < nl ? aux_col(A, col + (u32)li + 1, i) : 0;
+        d |= (u32)hi << (BITS - sh);
+    }
+    return d & ((1u << WB) - 1);
+}
+// mul_biguint_by_bool gadgets/biguint.rs:360-374 (limbs are canonical Goldilocks values, b is 0 or 1)
+template <class E>
+P2E_HD void aux_put_select(E& e, const u64* l, int nl, u64 b) {
+    P2E_UNROLL
+    for (int k = 0; k < NL; k++)
+        if (k < nl) e.put(b ? l[k] : 0);
+}
+// not(b), then the four products of curve_conditional_add gadgets/curve.rs:233-238
+template <class E>
+P2E_HD void aux_put_cond_add(E& e, const AuxArgs& A, const AuxItem& it, size_t i, u64 b) {
+    const u64 not_b = 1 - b;
+    e.put(not_b);
+    u64 l[NL];
+    aux_load_limbs(A, it.sumx, i, l, NL);
+    aux_put_select(e, l, NL, b);
+    aux_load_limbs(A, it.sumy, i, l, NL);
+    aux_put_select(e, l, NL, b);
+    aux_load_limbs(A, it.p1x, i, l, it.nlx);
+    aux_put_select(e, l, it.nlx, not_b);
+    aux_load_limbs(A, it.p1y, i, l, it.nly);
+    aux_put_select(e, l, it.nly, not_b);
+}
+
+template <class E>
+P2E_HD void body_aux(const AuxArgs& A, int item, size_t i) {
+    const AuxItem it = A.items[item];
+    E e = E::at(A.aux, A.ald, i, it.aux_col);
+    if (it.kind == AUX_SPLIT4 || it.kind == AUX_SPLIT2) {
+        u64 l[NL];
+        aux_load_limbs(A, it.a, i, l, it.nlx);
+        bool bad = false;
+        for (int k = 0; k < it.nlx; k++) {
+            bad = bad || (l[k] >> BITS) != 0;   // split_le_base(limb, 29) has no witness for a wider limb
+            for (int j = 0; j < BITS; j++) e.put((l[k] >> j) & 1);
+        }
+        if (bad) err_or(&A.err[i], ERR_LIMB_RANGE);
+        const int nbits = it.nlx * BITS;
+        if (it.kind == AUX_SPLIT4) {
+            for (int t = 0; 4 * t < nbits; t++) {
+                const u32 d = aux_digit<4>(A, it.a, it.nlx, t, i);
+                e.put(d & 3);    // lower = mul_add(b, two, a)
+                e.put(d >> 2);   // upper = mul_add(d, two, c)
+                e.put(d);        // mul_add(upper, four, lower)
+            }
+        } else {
+            for (int t = 0; 2 * t < nbits; t++) e.put(aux_digit<2>(A, it.a, it.nlx, t, i));
+        }
+    } else if (it.kind == AUX_FBWIN) {   // gadgets/curve_fixed_base.rs:56-61
+        const u32 d = aux_digit<4>(A, it.a, NL, (int)it.b, i);
+        const u64 is_zero = d == 0, should_add = 1 - is_zero;
+        e.put(is_zero);
+        e.put(should_add);
+        const Aff r = A.fbtab[it.b * 16 + d];   // slot 0 holds a copy of slot 1 (:56)
+        u64 l[NL];
+        aux_limbs_of(r.x, l);
+        aux_put_select(e, l, NL, 1);
+        aux_limbs_of(r.y, l);
+        aux_put_select(e, l, NL, 1);
+        aux_put_cond_add(e, A, it, i, should_add);
+    } else if (it.kind == AUX_MSMDIG) {  // gadgets/curve_msm.rs:67-71
+        const u32 idx = 4 * aux_digit<2>(A, it.c, 5, (int)it.b, i) + aux_digit<2>(A, it.a, 5, (int)it.b, i);
+        e.put(idx);
+        u64 l[NL];
+        aux_load_limbs(A, A.tab->tabx[idx], i, l, NL);
+        aux_put_select(e, l, NL, 1);
+        aux_load_limbs(A, A.tab->taby[idx], i, l, NL);
+        aux_put_select(e, l, NL, 1);
+        const u64 is_zero = idx == 0, should_add = 1 - is_zero;
+        e.put(is_zero);
+        e.put(should_add);
+        aux_put_cond_add(e, A, it, i, should_add);
+    } else {                             // AUX_CNEG gadgets/nonnative.rs:584-596
+        const u64 b = aux_col(A, it.a, i), not_b = 1 - b;
+        e.put(not_b);
+        u64 l[NL];
+        aux_load_limbs(A, it.sumx, i, l, NL);
+        aux_put_select(e, l, NL, b);
+        aux_load_limbs(A, it.p1x, i, l, it.nlx);
+        aux_put_select(e, l, it.nlx, not_b);
+    }
+    e.flush();
+}
+
+}  // namespace p2e

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/p2e.h"
+#include "aux.hpp"
 #include "consts.hpp"
 #include "pipeline.hpp"
 #include "prims.hpp"
@@ -77,6 +78,11 @@ __global__ __launch_bounds__(BS) void k_expand_runs(Program G, Buffers B, int it
     } else if (i < B.n) {
         body_expand_run<Emit>(G, B, i, it0, it1);
     }
+}
+// built-in-generator columns from the finished witness matrix: one (signature, item) per lane (aux.hpp)
+__global__ __launch_bounds__(BS) void k_aux(AuxArgs A, int item0) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    if (i < A.n) body_aux<Emit>(A, item0 + (int)blockIdx.y, i);
 }
 // err words -> caller's err bytes, valid bytes, flagged count
 __global__ __launch_bounds__(BS) void k_finalize(const u32* err32, const uint8_t* valid8, uint8_t* err_out,
@@ -242,9 +248,16 @@ static void set_error(const std::string& s) { g_last_error = s; }
 
 struct DeviceProgram {
     Program prog;
-    OpDesc* d_ops = nullptr;
+    OpDesc* d_ops = nullptr;        // with the run marks of ctx->run_iters (F_NO_AFFINE)
+    OpDesc* d_ops_plain = nullptr;  // without: every op expanded on its own (small batches)
     std::vector<OpDesc> h_ops;
     std::vector<host::GenOp> gens;
+    // built-in-generator columns (aux.hpp)
+    std::vector<AuxItem> aux_items;
+    std::vector<host::AuxGen> aux_gens;
+    AuxTables aux_tab{};
+    AuxItem* d_aux_items = nullptr;
+    AuxTables* d_aux_tab = nullptr;
 };
 
 struct p2e_ctx {
@@ -260,13 +273,17 @@ struct p2e_ctx {
     static constexpr int MAX_SEG = 2 * MAX_PIECES + 2;
     hipStream_t st_msm = nullptr, st_fixed = nullptr;
     hipEvent_t ev_fork = nullptr, ev_fixed = nullptr, ev_piece[MAX_SEG] = {}, ev_binv[MAX_SEG] = {};
-    hipEvent_t ev_c0[MAX_SEG] = {}, ev_c1[MAX_SEG] = {};   // around every k_expand launch
+    // one event pair around every expansion launch; kind 0 = k_expand (op by op), 1 = k_expand_runs
+    static constexpr int MAX_EXPAND = 2 * MAX_SEG;
+    hipEvent_t ev_c0[MAX_EXPAND] = {}, ev_c1[MAX_EXPAND] = {};
     int n_expand = 0;
-    double expand_cols[MAX_SEG] = {};
-    float expand_ms_sum = 0.f;
-    double expand_cols_sum = 0.0;
+    double expand_cols[MAX_EXPAND] = {};
+    int expand_kind[MAX_EXPAND] = {};
     int msm_pieces = 8, fixed_pieces = 2;   // one Montgomery inversion batch per piece
     int run_iters = 9;                      // MSM-loop iterations per expansion run (0: expand op by op)
+    // A run is walked by ONE lane, so a launch of r runs has only r * n/64 waves: below this batch size the
+    // 1024 SIMDs are better filled by one workgroup row per op (2^10 glv_mul fills: 3.0 ms against 9.5 ms)
+    size_t runs_min_n = 49152;
     Aff* d_cpts = nullptr;
     Aff* d_fbtab = nullptr;
     DeviceProgram progs[2];
@@ -275,7 +292,7 @@ struct p2e_ctx {
     unsigned long long* d_counter = nullptr;
     unsigned long long* h_counter = nullptr;  // pinned
     hipEvent_t ev[6] = {};   // [0],[1] around k_scalar, [5] end of the call (2..4 unused)
-    float phase_ms[5] = {0, 0, 0, 0, 0};
+    float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool have_phases = false;
 };
 
@@ -287,10 +304,16 @@ static const DeviceProgram& host_program(int program) {
         b0.verify_secp256k1_message_circuit();
         P[0].prog = b0.prog;
         P[0].gens = b0.gens;
+        P[0].aux_items = b0.aux_items;
+        P[0].aux_gens = b0.aux_gens;
+        P[0].aux_tab = b0.aux_tab;
         host::ScheduleBuilder b1;
         b1.glv_mul_circuit();
         P[1].prog = b1.prog;
         P[1].gens = b1.gens;
+        P[1].aux_items = b1.aux_items;
+        P[1].aux_gens = b1.aux_gens;
+        P[1].aux_tab = b1.aux_tab;
     });
     return P[program];
 }
@@ -357,7 +380,10 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     if (stream) {
         c->stream = (hipStream_t)stream;
     } else {
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        // A BLOCKING stream: it keeps the implicit ordering with the legacy default stream, which is what a caller
+        // that passes "its current stream" means when that stream is the default one (handle 0, indistinguishable
+        // from NULL): e.g. torch.zeros(...) on torch's default stream followed by a call that writes the tensor.
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamDefault));
         c->own_stream = true;
     }
     const host::Consts& C = host::consts();
@@ -369,12 +395,23 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         int v = atoi(env);
         if (v >= 0 && v <= MSM_DIGITS) c->run_iters = v;
     }
+    if (const char* env = getenv("P2E_RUNS_MIN_N")) c->runs_min_n = (size_t)strtoull(env, nullptr, 10);
     for (int p = 0; p < 2; p++) {
         c->progs[p].prog = host_program(p).prog;
         std::vector<OpDesc> ops = host_ops(p, c->run_iters);
         c->progs[p].h_ops = ops;
         HIP_TRY(hipMalloc(&c->progs[p].d_ops, sizeof(OpDesc) * ops.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_ops, ops.data(), sizeof(OpDesc) * ops.size(), hipMemcpyHostToDevice));
+        const DeviceProgram& HP = host_program(p);
+        c->progs[p].aux_tab = HP.aux_tab;
+        c->progs[p].aux_items = HP.aux_items;
+        HIP_TRY(hipMalloc(&c->progs[p].d_aux_items, sizeof(AuxItem) * HP.aux_items.size()));
+        HIP_TRY(hipMemcpy(c->progs[p].d_aux_items, HP.aux_items.data(), sizeof(AuxItem) * HP.aux_items.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&c->progs[p].d_aux_tab, sizeof(AuxTables)));
+        HIP_TRY(hipMemcpy(c->progs[p].d_aux_tab, &HP.aux_tab, sizeof(AuxTables), hipMemcpyHostToDevice));
+        std::vector<OpDesc> plain = host_ops(p, 0);
+        HIP_TRY(hipMalloc(&c->progs[p].d_ops_plain, sizeof(OpDesc) * plain.size()));
+        HIP_TRY(hipMemcpy(c->progs[p].d_ops_plain, plain.data(), sizeof(OpDesc) * plain.size(), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMalloc(&c->d_counter, sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(&c->h_counter, sizeof(unsigned long long)));
@@ -407,7 +444,12 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_cpts);
     (void)hipFree(c->d_fbtab);
-    for (auto& p : c->progs) (void)hipFree(p.d_ops);
+    for (auto& p : c->progs) {
+        (void)hipFree(p.d_ops);
+        (void)hipFree(p.d_ops_plain);
+        (void)hipFree(p.d_aux_items);
+        (void)hipFree(p.d_aux_tab);
+    }
     (void)hipFree(c->scratch);
     (void)hipFree(c->d_counter);
     (void)hipHostFree(c->h_counter);
@@ -438,24 +480,28 @@ extern "C" int p2e_sync(p2e_ctx* c) {
     if (c->have_phases) {
         (void)hipEventElapsedTime(&c->phase_ms[0], c->ev[0], c->ev[1]);   // scalar kernel
         (void)hipEventElapsedTime(&c->phase_ms[4], c->ev[0], c->ev[5]);   // whole call
-        c->expand_ms_sum = 0.f;
-        c->expand_cols_sum = 0.0;
+        double cnt[2] = {0, 0}, cols[2] = {0, 0}, sum_ms[2] = {0, 0};
         for (int k = 0; k < c->n_expand; k++) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, c->ev_c0[k], c->ev_c1[k]);
-            c->expand_ms_sum += ms;
-            c->expand_cols_sum += c->expand_cols[k];
+            const int kind = c->expand_kind[k];
+            cnt[kind] += 1;
+            cols[kind] += c->expand_cols[k];
+            sum_ms[kind] += ms;
         }
-        c->phase_ms[1] = (float)c->n_expand;         // number of k_expand launches
-        c->phase_ms[2] = (float)c->expand_cols_sum;  // columns they wrote (per signature)
-        c->phase_ms[3] = c->expand_ms_sum;           // their summed durations
+        for (int kind = 0; kind < 2; kind++) {       // [1..3] k_expand, [5..7] k_expand_runs
+            const int o = kind == 0 ? 1 : 5;
+            c->phase_ms[o] = (float)cnt[kind];       // launches
+            c->phase_ms[o + 1] = (float)cols[kind];  // columns they wrote (per signature)
+            c->phase_ms[o + 2] = (float)sum_ms[kind];  // their summed durations
+        }
     }
     return (int)*c->h_counter;
 }
 
 extern "C" int p2e_last_phase_ms(p2e_ctx* c, float* out, int cap) {
     if (!c || !out) return P2E_E_INVALID;
-    int k = cap < 5 ? cap : 5;
+    int k = cap < 8 ? cap : 8;
     for (int i = 0; i < k; i++) out[i] = c->phase_ms[i];
     return k;
 }
@@ -739,7 +785,8 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     B.src = (uint16_t*)(base + L.src);
     B.cpts = c->d_cpts;
     B.fbtab = c->d_fbtab;
-    B.ops = DP.d_ops;
+    const int run_iters = n >= c->runs_min_n ? c->run_iters : 0;
+    B.ops = run_iters > 0 ? DP.d_ops : DP.d_ops_plain;
     ZERO_COUNTER(c);
     unsigned gx = (unsigned)((n + BS - 1) / BS);
     c->n_expand = 0;
@@ -780,7 +827,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         // the loop, cut at run boundaries into msm_pieces - 1 groups + the trailing unblinding add
         const int lo0 = G.chain_begin[0], hi0 = G.chain_end[0];
         const int lb = G.msm_loop_begin, iters = G.msm_loop_iters, le = lb + 3 * iters;
-        const int R = c->run_iters > 0 ? c->run_iters : 1;
+        const int R = run_iters > 0 ? run_iters : 1;
         const int nruns = (iters + R - 1) / R;
         int groups = c->msm_pieces > 1 ? c->msm_pieces - 1 : 1;
         if (groups > nruns) groups = nruns;
@@ -791,14 +838,14 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             int take = (nruns - run + rem - 1) / rem;
             int it0 = run * R, it1 = (run + take) * R < iters ? (run + take) * R : iters;
             Seg sg{lb + 3 * it0, lb + 3 * it1, lb + 3 * it1 - lo0, c->st_msm, false, 0, 0, it0, it1};
-            if (c->run_iters == 0) {   // run expansion disabled: op by op
+            if (run_iters == 0) {   // no run expansion: op by op
                 sg.s_lo = sg.lo;
                 sg.s_hi = sg.hi;
                 sg.it0 = sg.it1 = 0;
             }
             if (g == groups - 1) {     // trailing ops of the chain (the unblinding add)
                 sg.hi = hi0;
-                if (c->run_iters == 0) sg.s_hi = hi0; else { sg.s_lo = le; sg.s_hi = hi0; }
+                if (run_iters == 0) sg.s_hi = hi0; else { sg.s_lo = le; sg.s_hi = hi0; }
                 sg.order = hi0 - lo0;
             }
             segs[ns++] = sg;
@@ -861,27 +908,36 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             HIP_TRY(hipEventRecord(c->ev_binv[k], st_b));
         }
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_binv[k], 0));
-        int e = c->n_expand++;
-        HIP_TRY(hipEventRecord(c->ev_c0[e], c->stream));
+        auto cols_of = [&](int lo, int hi) {
+            double cw = 0;
+            for (int t = lo; t < hi; t++)
+                cw += DP.h_ops[t].kind == OP_DBL ? COLS_DBL : DP.h_ops[t].kind == OP_CADD ? COLS_CADD : COLS_ADD;
+            return cw;
+        };
         if (sg.it1 > sg.it0) {
-            const int R = c->run_iters;
+            const int R = run_iters;
             const unsigned nr = (unsigned)((sg.it1 - sg.it0 + R - 1) / R);
+            const int e = c->n_expand++;
+            HIP_TRY(hipEventRecord(c->ev_c0[e], c->stream));
             if (gx_wide)
                 hipLaunchKernelGGL(k_expand_runs<true>, dim3(gx_wide, nr), dim3(BS), 0, c->stream, G, B, sg.it0, R, sg.it1, (size_t)0);
             if (gx_tail)
                 hipLaunchKernelGGL(k_expand_runs<false>, dim3(gx_tail, nr), dim3(BS), 0, c->stream, G, B, sg.it0, R, sg.it1, n_wide);
+            HIP_TRY(hipEventRecord(c->ev_c1[e], c->stream));
+            c->expand_kind[e] = 1;
+            c->expand_cols[e] = cols_of(G.msm_loop_begin + 3 * sg.it0, G.msm_loop_begin + 3 * sg.it1);
         }
         if (sg.s_hi > sg.s_lo) {
+            const int e = c->n_expand++;
+            HIP_TRY(hipEventRecord(c->ev_c0[e], c->stream));
             if (gx_wide)
                 hipLaunchKernelGGL(k_expand<true>, dim3(gx_wide, (unsigned)(sg.s_hi - sg.s_lo)), dim3(BS), 0, c->stream, G, B, sg.s_lo, (size_t)0);
             if (gx_tail)
                 hipLaunchKernelGGL(k_expand<false>, dim3(gx_tail, (unsigned)(sg.s_hi - sg.s_lo)), dim3(BS), 0, c->stream, G, B, sg.s_lo, n_wide);
+            HIP_TRY(hipEventRecord(c->ev_c1[e], c->stream));
+            c->expand_kind[e] = 0;
+            c->expand_cols[e] = cols_of(sg.s_lo, sg.s_hi);
         }
-        HIP_TRY(hipEventRecord(c->ev_c1[e], c->stream));
-        double cols_written = 0;
-        for (int t = sg.lo; t < sg.hi; t++)
-            cols_written += DP.h_ops[t].kind == OP_DBL ? COLS_DBL : DP.h_ops[t].kind == OP_CADD ? COLS_CADD : COLS_ADD;
-        c->expand_cols[e] = cols_written;
     }
     HIP_TRY(hipEventRecord(c->ev[5], c->stream));
     hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, B.err, B.valid, err, valid, n, c->d_counter);
@@ -917,9 +973,52 @@ extern "C" long p2e_columns_to_rows(p2e_ctx* c, const uint64_t* cols, size_t ld,
     return S.done(finish_call(c));
 }
 
+extern "C" long p2e_aux_witness_batch(p2e_ctx* c, int program, const uint8_t* pky32, const uint64_t* cols, size_t ld,
+                                      uint64_t* aux, size_t ld_aux, size_t n, uint8_t* err) {
+    if (bad_common(c, n, ld) || program < 0 || program > 1 || !pky32 || !cols || !aux || !err || ld_aux < n) {
+        if (c && ld_aux < n) set_error("ld_aux < n");
+        return P2E_E_INVALID;
+    }
+    if (n == 0) return 0;
+    const DeviceProgram& DP = c->progs[program];
+    Staged S(c);
+    pky32 = S.in(pky32, 32 * n);
+    cols = S.in(cols, (size_t)DP.prog.num_cols * ld * 8);
+    aux = S.out(aux, (size_t)DP.aux_tab.num_aux_cols * ld_aux * 8);
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    if (int rc = ensure_scratch(c, n * sizeof(u32))) return S.done(rc);
+    ZERO_COUNTER(c);
+    u32* err32 = (u32*)c->scratch;
+    HIP_TRY(hipMemsetAsync(err32, 0, n * sizeof(u32), c->stream));
+    AuxArgs A{cols, ld, aux, ld_aux, n, pky32, c->d_cpts, c->d_fbtab, DP.d_aux_items, DP.d_aux_tab, err32};
+    const unsigned gx = (unsigned)((n + BS - 1) / BS);
+    hipLaunchKernelGGL(k_aux, dim3(gx, (unsigned)DP.aux_items.size()), dim3(BS), 0, c->stream, A, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, err32, (const uint8_t*)nullptr, err,
+                       (uint8_t*)nullptr, n, c->d_counter);
+    c->have_phases = false;
+    return S.done(finish_call(c));
+}
+
 // ====================================================================================================
 // host-only entry points
 // ====================================================================================================
+extern "C" long p2e_aux_describe(int program, p2e_aux_desc* out, size_t cap) {
+    if (program < 0 || program > 1) return P2E_E_INVALID;
+    const auto& g = host_program(program).aux_gens;
+    for (size_t i = 0; i < g.size() && i < cap && out; i++) {
+        out[i].kind = g[i].kind;
+        out[i].first_col = g[i].col;
+        out[i].num_cols = g[i].ncols;
+        std::memset(out[i].label, 0, sizeof out[i].label);
+        std::strncpy(out[i].label, g[i].label.c_str(), sizeof(out[i].label) - 1);
+    }
+    return (long)g.size();
+}
+extern "C" long p2e_aux_num_cols(int program) {
+    if (program < 0 || program > 1) return P2E_E_INVALID;
+    return host_program(program).aux_tab.num_aux_cols;
+}
 extern "C" long p2e_schedule_describe(int program, p2e_gen_desc* out, size_t cap) {
     if (program < 0 || program > 1) return P2E_E_INVALID;
     const auto& g = host_program(program).gens;

@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include "aux.hpp"
+#include "consts.hpp"
 #include "pipeline.hpp"
 
 namespace p2e {
@@ -32,14 +34,28 @@ struct GenOp {
     std::string label;
 };
 
-// symbolic NonNativeTarget: the hot path never needs its value on the host, only its identity
+// symbolic NonNativeTarget: the hot path never needs its value on the host, only its identity and, for the
+// built-in-generator columns (aux.hpp), where its limbs live: an output column, a constant, or a caller input
 struct NonNativeTarget {
     int field;
+    u32 col = AUX_SRC_NONE;  // first column of its limbs in the witness matrix, or an AUX_SRC_* code
+    int nl = NL;             // limbs the target really has (constants and k1, k2 have fewer than 9)
+};
+// symbolic BoolTarget: the witness column holding it
+struct BoolTarget {
+    u32 col;
 };
 // symbolic AffinePointTarget: where the GPU finds the point
 struct AffinePointTarget {
     u32 ref;
     bool z_one;  // known to be stored in affine form before phase B (constants, inputs)
+    u32 xcol = AUX_SRC_NONE, ycol = AUX_SRC_NONE;  // limb columns of x and y (or AUX_SRC_* codes)
+    int nlx = NL, nly = NL;
+};
+struct AuxGen {   // one entry of the built-in-generator column map (p2e_aux_describe)
+    int kind;
+    u32 col, ncols;
+    std::string label;
 };
 
 class ScheduleBuilder {
@@ -47,33 +63,58 @@ public:
     std::vector<GenOp> gens;
     std::vector<OpDesc> ops;
     Program prog{};
+    // built-in-generator columns: items for k_aux + their column map
+    std::vector<AuxItem> aux_items;
+    std::vector<AuxGen> aux_gens;
+    AuxTables aux_tab{};
 
-    // ---- CircuitBuilderNonNative ----
+    // ---- CircuitBuilderNonNative ----  (every result target = the first 9 columns its generator writes)
     NonNativeTarget add_nonnative(NonNativeTarget a, NonNativeTarget, bool /*range_check*/ = false) {
-        gen(GEN_ADD, a.field, 10);
-        return a;
+        return {a.field, gen(GEN_ADD, a.field, 10), NL};
     }
     NonNativeTarget sub_nonnative(NonNativeTarget a, NonNativeTarget, bool = false) {
-        gen(GEN_SUB, a.field, 10);
-        return a;
+        return {a.field, gen(GEN_SUB, a.field, 10), NL};
     }
     NonNativeTarget add_many_nonnative(const std::vector<NonNativeTarget>& xs, bool = false) {
         if (xs.size() == 1) return xs[0];
-        gen(GEN_ADD_MANY, xs[0].field, 10);
-        return xs[0];
+        return {xs[0].field, gen(GEN_ADD_MANY, xs[0].field, 10), NL};
     }
     NonNativeTarget mul_nonnative(NonNativeTarget a, NonNativeTarget, bool = false) {
-        gen(GEN_MUL, a.field, 51);  // MulNonnativeGate r,q,check_sum (35) + CheckSumGate b (16)
-        return a;
+        // MulNonnativeGate r,q,check_sum (35) + CheckSumGate b (16); the product target = the r wires
+        return {a.field, gen(GEN_MUL, a.field, 51), NL};
     }
     NonNativeTarget inv_nonnative(NonNativeTarget a, bool = false) {
-        gen(GEN_INV, a.field, 18);
-        return a;
+        return {a.field, gen(GEN_INV, a.field, 18), NL};
     }
     NonNativeTarget neg_nonnative(NonNativeTarget a, bool = false) { return sub_nonnative(a, a); }
-    NonNativeTarget nonnative_conditional_neg(NonNativeTarget x, bool = false) {
+    // gadgets/nonnative.rs:584-596: not(b), neg, neg * b, x * not_b, add
+    NonNativeTarget nonnative_conditional_neg(NonNativeTarget x, BoolTarget b, bool = false) {
+        AuxItem it{};
+        it.kind = AUX_CNEG;
+        it.a = b.col;
         NonNativeTarget neg = neg_nonnative(x);
+        it.sumx = neg.col;
+        it.p1x = x.col;
+        it.nlx = (uint8_t)x.nl;
+        aux(it, 1 + NL + (u32)x.nl);
         return add_nonnative(neg, x);
+    }
+    // gadgets/split_nonnative.rs:25-50 / :52-72: split_le_base bits of every limb, then the digits built from them
+    void split_nonnative_to_4_bit_limbs(NonNativeTarget v) {
+        AuxItem it{};
+        it.kind = AUX_SPLIT4;
+        it.a = v.col;
+        it.nlx = (uint8_t)v.nl;
+        const u32 nbits = (u32)v.nl * BITS;
+        aux(it, nbits + 3 * ((nbits + 3) / 4));
+    }
+    void split_nonnative_to_2_bit_limbs(NonNativeTarget v) {
+        AuxItem it{};
+        it.kind = AUX_SPLIT2;
+        it.a = v.col;
+        it.nlx = (uint8_t)v.nl;
+        const u32 nbits = (u32)v.nl * BITS;
+        aux(it, nbits + (nbits + 1) / 2);
     }
 
     // ---- CircuitBuilderCurve ----
@@ -99,22 +140,36 @@ public:
     AffinePointTarget curve_conditional_add(AffinePointTarget p1, AffinePointTarget p2, bool = false) {
         return curve_op(OP_CADD, p1, p2);
     }
-    AffinePointTarget constant_affine_point(int which) { return {make_ref(R_CONST, (u32)which), true}; }
+    AffinePointTarget constant_affine_point(int which) {
+        const Consts& C = consts();
+        return {make_ref(R_CONST, (u32)which), true, AUX_SRC_CONST | (u32)(2 * which), AUX_SRC_CONST | (u32)(2 * which + 1),
+                const_num_limbs(C.cpts[which].x), const_num_limbs(C.cpts[which].y)};
+    }
 
     // ---- fixed_base_curve_mul_circuit(builder, G, scalar) ----
-    AffinePointTarget fixed_base_curve_mul_circuit() {
+    AffinePointTarget fixed_base_curve_mul_circuit(NonNativeTarget scalar) {
+        split_nonnative_to_4_bit_limbs(scalar);
         AffinePointTarget result = constant_affine_point(CONST_RANDO);
         for (int w = 0; w < FB_WINDOWS; w++) {
             Scope s(this, "win" + std::to_string(w));
-            AffinePointTarget r{make_ref(R_FBTAB, (u32)w), true};  // random_access_curve_points(limb, muls_point)
+            // is_equal(limb, zero), not, random_access_curve_points(limb, muls_point), curve_conditional_add
+            AffinePointTarget r{make_ref(R_FBTAB, (u32)w), true};
+            AuxItem it = select_item(AUX_FBWIN, result);
+            it.a = scalar.col;
+            it.b = (u32)w;
             result = curve_conditional_add(result, r);
+            it.sumx = ops.back().col + COL_ADD_X3;
+            it.sumy = ops.back().col + COL_ADD_Y3;
+            aux(it, 2 + 2 * NL + 1 + 2 * NL + (u32)it.nlx + (u32)it.nly);
         }
         Scope s(this, "unblind");
         return curve_add(result, constant_affine_point(CONST_NEG_RANDO), true);
     }
 
     // ---- curve_msm_circuit(builder, p, q, n, m) ----
-    AffinePointTarget curve_msm_circuit(AffinePointTarget p, AffinePointTarget q) {
+    AffinePointTarget curve_msm_circuit(AffinePointTarget p, AffinePointTarget q, NonNativeTarget n, NonNativeTarget m) {
+        split_nonnative_to_2_bit_limbs(n);
+        split_nonnative_to_2_bit_limbs(m);
         AffinePointTarget rando = constant_affine_point(CONST_RANDO);
         AffinePointTarget neg_rando = constant_affine_point(CONST_NEG_RANDO);
         AffinePointTarget pre[16];
@@ -135,15 +190,27 @@ public:
             for (int i = 1; i < 4; i++)
                 for (int j = 1; j < 4; j++) pre[i + 4 * j] = curve_add(pre[i], pre[4 * j]);
         }
-        for (int i = 0; i < 16; i++) prog.msm_tab[i] = pre[i].ref;
+        for (int i = 0; i < 16; i++) {
+            prog.msm_tab[i] = pre[i].ref;
+            aux_tab.tabx[i] = pre[i].xcol;
+            aux_tab.taby[i] = pre[i].ycol;
+        }
         AffinePointTarget result = rando;
         prog.msm_loop_begin = (int32_t)ops.size();
         prog.msm_loop_iters = MSM_DIGITS;
         for (int d = MSM_DIGITS - 1; d >= 0; d--) {
             Scope s(this, "digit" + std::to_string(d));
             result = curve_repeated_double(result, 2);
-            AffinePointTarget r{make_ref(R_MSMTAB, (u32)d), false};  // random_access_curve_points(index, pre)
+            // mul_add(four, limb_m, limb_n), random_access_curve_points(index, pre), is_equal, not, conditional add
+            AffinePointTarget r{make_ref(R_MSMTAB, (u32)d), false};
+            AuxItem it = select_item(AUX_MSMDIG, result);
+            it.a = n.col;
+            it.c = m.col;
+            it.b = (u32)d;
             result = curve_conditional_add(result, r);
+            it.sumx = ops.back().col + COL_ADD_X3;
+            it.sumy = ops.back().col + COL_ADD_Y3;
+            aux(it, 1 + 2 * NL + 2 + 1 + 2 * NL + (u32)it.nlx + (u32)it.nly);
         }
         Scope s(this, "unblind");
         return curve_add(result, constant_affine_point(CONST_NEG_RANDO_146), true);
@@ -154,9 +221,14 @@ public:
         Scope s(this, "decompose");
         prog.sc.glv = (int32_t)col_;
         NonNativeTarget f{FIELD_SCALAR};
-        gen(GEN_GLV, FIELD_SCALAR, 12);
-        NonNativeTarget k1 = nonnative_conditional_neg(f);
-        NonNativeTarget k2 = nonnative_conditional_neg(f);
+        // GLVDecompositionGenerator outputs: k1[5], k2[5], k1_neg, k2_neg
+        const u32 g = gen(GEN_GLV, FIELD_SCALAR, 12);
+        glv_k1_ = {FIELD_SCALAR, g, 5};
+        glv_k2_ = {FIELD_SCALAR, g + 5, 5};
+        glv_k1_neg_ = {g + 10};
+        glv_k2_neg_ = {g + 11};
+        NonNativeTarget k1 = nonnative_conditional_neg(glv_k1_, glv_k1_neg_);
+        NonNativeTarget k2 = nonnative_conditional_neg(glv_k2_, glv_k2_neg_);
         NonNativeTarget sb = mul_nonnative(f, k2);
         add_nonnative(sb, k1, true);
     }
@@ -164,15 +236,17 @@ public:
         (void)chain_slot_base_hint;
         decompose_secp256k1_scalar();
         NonNativeTarget b{FIELD_BASE};
+        NonNativeTarget py{FIELD_BASE, AUX_SRC_INPUT_PY, NL};   // the caller's pk.y target (9 limbs)
         prog.sc.beta_x = (int32_t)col_;
-        mul_nonnative(b, b, true);
+        NonNativeTarget beta_px = mul_nonnative(b, b, true);
         prog.sc.neg_p = (int32_t)col_;
-        nonnative_conditional_neg(b, true);  // curve_conditional_neg(p, k1_neg)
+        NonNativeTarget y1 = nonnative_conditional_neg(py, glv_k1_neg_, true);  // curve_conditional_neg(p, k1_neg)
         prog.sc.neg_sp = (int32_t)col_;
-        nonnative_conditional_neg(b, true);  // curve_conditional_neg(sp, k2_neg)
+        NonNativeTarget y2 = nonnative_conditional_neg(py, glv_k2_neg_, true);  // curve_conditional_neg(sp, k2_neg)
         Scope s(this, "msm");
-        AffinePointTarget p{make_ref(R_SLOT, SLOT_P_PLACEHOLDER), true}, sp{make_ref(R_SLOT, SLOT_SP_PLACEHOLDER), true};
-        return curve_msm_circuit(p, sp);
+        AffinePointTarget p{make_ref(R_SLOT, SLOT_P_PLACEHOLDER), true, AUX_SRC_NONE, y1.col};
+        AffinePointTarget sp{make_ref(R_SLOT, SLOT_SP_PLACEHOLDER), true, beta_px.col, y2.col};
+        return curve_msm_circuit(p, sp, glv_k1_, glv_k2_);
     }
 
     // ---- verify_secp256k1_message_circuit(builder, msg, sig, pk) ----
@@ -184,14 +258,14 @@ public:
         prog.sc.inv_s = (int32_t)col_;
         NonNativeTarget c = inv_nonnative(s);
         prog.sc.u1 = (int32_t)col_;
-        mul_nonnative(s, c, true);
+        NonNativeTarget u1 = mul_nonnative(s, c, true);
         prog.sc.u2 = (int32_t)col_;
         mul_nonnative(s, c, true);
         int c0 = (int)ops.size();
         AffinePointTarget point1, point2;
         {
             Scope sc(this, "fixed_base");
-            point1 = fixed_base_curve_mul_circuit();
+            point1 = fixed_base_curve_mul_circuit(u1);
         }
         int c1 = (int)ops.size();
         {
@@ -242,8 +316,10 @@ public:
 
 private:
     static constexpr u32 SLOT_P_PLACEHOLDER = 0xFFFF00, SLOT_SP_PLACEHOLDER = 0xFFFF01;
-    u32 col_ = 0;
+    u32 col_ = 0, aux_col_ = 0;
     int num_cadd_ = 0;
+    NonNativeTarget glv_k1_{FIELD_SCALAR}, glv_k2_{FIELD_SCALAR};
+    BoolTarget glv_k1_neg_{0}, glv_k2_neg_{0};
     std::vector<std::string> path_;
 
     struct Scope {
@@ -256,9 +332,34 @@ private:
         for (size_t i = 0; i < path_.size(); i++) s += (i ? "/" : "") + path_[i];
         return s;
     }
-    void gen(int kind, int field, u32 ncols) {
+    u32 gen(int kind, int field, u32 ncols) {   // returns the generator's first column
         gens.push_back({kind, field, col_, ncols, label()});
         col_ += ncols;
+        return col_ - ncols;
+    }
+    void aux(AuxItem it, u32 ncols) {
+        it.aux_col = aux_col_;
+        it.ncols = ncols;
+        aux_items.push_back(it);
+        aux_gens.push_back({(int)it.kind, aux_col_, ncols, label()});
+        aux_col_ += ncols;
+    }
+    // the part of a window's item that comes from curve_conditional_add(p1, ...): where p1's limbs live
+    static AuxItem select_item(AuxKind kind, const AffinePointTarget& p1) {
+        AuxItem it{};
+        it.kind = kind;
+        it.p1x = p1.xcol;
+        it.p1y = p1.ycol;
+        it.nlx = (uint8_t)p1.nlx;
+        it.nly = (uint8_t)p1.nly;
+        return it;
+    }
+    static int const_num_limbs(const U256& v) {   // constant_biguint gadgets/biguint.rs:165-175 via convert_base :27-51
+        u32 l[NL];
+        split29(v, l);
+        int n = NL;
+        while (n > 0 && l[n - 1] == 0) n--;
+        return n;
     }
     AffinePointTarget curve_op(OpKind kind, AffinePointTarget p1, AffinePointTarget p2) {
         OpDesc d{};
@@ -300,10 +401,12 @@ private:
         AffinePointTarget out;
         if (kind == OP_CADD) {
             d.cadd_idx = (uint16_t)num_cadd_;
-            out = {make_ref(R_DYN, (u32)num_cadd_), false};
+            out = {make_ref(R_DYN, (u32)num_cadd_), false, d.col + COL_CADD_X, d.col + COL_CADD_Y};
             num_cadd_++;
+        } else if (kind == OP_DBL) {
+            out = {make_ref(R_SLOT, t), false, d.col + COL_DBL_X3, d.col + COL_DBL_Y3};
         } else {
-            out = {make_ref(R_SLOT, t), false};
+            out = {make_ref(R_SLOT, t), false, d.col + COL_ADD_X3, d.col + COL_ADD_Y3};
         }
         ops.push_back(d);
         return out;
@@ -315,6 +418,7 @@ private:
         prog.num_slots = prog.num_ops + 2;
         prog.num_cadd = num_cadd_;
         prog.num_cols = (int32_t)col_;
+        aux_tab.num_aux_cols = aux_col_;
         auto fix = [&](u32& r) {
             if (ref_kind(r) == R_SLOT && ref_id(r) == SLOT_P_PLACEHOLDER) r = make_ref(R_SLOT, (u32)prog.slot_p);
             if (ref_kind(r) == R_SLOT && ref_id(r) == SLOT_SP_PLACEHOLDER) r = make_ref(R_SLOT, (u32)prog.slot_sp);

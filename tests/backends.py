@@ -27,6 +27,13 @@ class OracleBackend:
     verify = staticmethod(lambda *a: oracle_c.verify_witness(*a))
     glv_mul = staticmethod(lambda *a: oracle_c.glv_mul_witness(*a))
 
+    @staticmethod
+    def aux(program, inputs):
+        """(cols, aux, err): the oracle's own walk records both matrices."""
+        f = oracle_c.verify_witness_aux if program == 0 else oracle_c.glv_mul_witness_aux
+        cols, aux, err, _flags = f(*inputs)
+        return cols, aux, err
+
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
@@ -42,7 +49,7 @@ class EmuBackend:
     def __init__(self):
         self.L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libp2e_emu.so"))
         for f in ("emu_verify", "emu_glv_mul", "emu_mul", "emu_checksum", "emu_add", "emu_sub", "emu_add_many",
-                  "emu_inv", "emu_glv", "emu_split", "emu_pack"):
+                  "emu_inv", "emu_glv", "emu_split", "emu_pack", "emu_aux", "emu_aux_num_cols"):
             getattr(self.L, f).restype = C.c_long
 
     def mul(self, field, x, y):
@@ -124,6 +131,21 @@ class EmuBackend:
         return cols, err, valid
 
 
+def _emu_aux(self, program, inputs):
+    """hot-path columns from this backend's own pipeline, then the aux pass over them"""
+    cols, err, _valid = (self.verify if program == 0 else self.glv_mul)(*inputs)
+    cols = np.ascontiguousarray(np.asarray(cols).view(np.uint64))
+    n = cols.shape[1]
+    pky = np.ascontiguousarray(inputs[4] if program == 0 else inputs[1], np.uint8)
+    aux = _z(int(self.L.emu_aux_num_cols(C.c_int(program))), n)
+    aerr = np.zeros(n, np.uint8)
+    self.L.emu_aux(C.c_int(program), _p(pky), _p(cols), C.c_size_t(n), _p(aux), C.c_size_t(n), C.c_size_t(n), _p(aerr))
+    return cols, aux, np.asarray(err) | aerr
+
+
+EmuBackend.aux = _emu_aux
+
+
 class GpuBackend:
     """The product, through the C ABI, host-pointer mode (numpy in / numpy out)."""
     name = "gpu"
@@ -168,3 +190,9 @@ class GpuBackend:
 
     def glv_mul(self, px, py, k):
         return self.ctx.glv_mul_witness_batch(*[self._c(a, np.uint8) for a in (px, py, k)])[:3]
+
+    def aux(self, program, inputs):
+        cols, err, _valid = (self.verify if program == 0 else self.glv_mul)(*inputs)
+        pky = self._c(inputs[4] if program == 0 else inputs[1], np.uint8)
+        aux, aerr, _bad = self.ctx.aux_witness_batch(program, pky, cols)
+        return np.asarray(cols).view(np.uint64), np.asarray(aux).view(np.uint64), np.asarray(err) | np.asarray(aerr)

@@ -168,6 +168,36 @@ long emu_glv_mul(const uint8_t* px, const uint8_t* py, const uint8_t* k, uint64_
                  uint8_t* err, uint8_t* valid, int chunk, int run_iters) {
     return run(1, k, k, k, px, py, cols, n, ld, err, valid, chunk, run_iters);
 }
+// built-in-generator columns from a finished witness matrix (aux.hpp: the body k_aux runs)
+long emu_aux(int program, const uint8_t* pky, const uint64_t* cols, size_t ld, uint64_t* aux, size_t ald, size_t n,
+             uint8_t* err) {
+    host::ScheduleBuilder sb;
+    if (program == 0)
+        sb.verify_secp256k1_message_circuit();
+    else
+        sb.glv_mul_circuit();
+    const host::Consts& C = host::consts();
+    std::vector<u32> err32(n);
+    AuxArgs A{cols, ld, aux, ald, n, pky, C.cpts, C.fbtab.data(), sb.aux_items.data(), &sb.aux_tab, err32.data()};
+    for (int item = 0; item < (int)sb.aux_items.size(); item++) {
+#pragma omp parallel for
+        for (long long i = 0; i < (long long)n; i++) body_aux<Emit>(A, item, (size_t)i);
+    }
+    long bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        err[i] = (uint8_t)err32[i];
+        bad += err32[i] != 0;
+    }
+    return bad;
+}
+long emu_aux_num_cols(int program) {
+    host::ScheduleBuilder sb;
+    if (program == 0)
+        sb.verify_secp256k1_message_circuit();
+    else
+        sb.glv_mul_circuit();
+    return (long)sb.aux_tab.num_aux_cols;
+}
 #define LOOP(expr)                                  \
     long bad = 0;                                   \
     for (size_t i = 0; i < n; i++) {                \

@@ -130,6 +130,25 @@ def check_glv_mul_golden(be):
     assert np.array_equal(np.asarray(got).view(np.uint64), g["cols"])
 
 
+def check_aux_golden(be):
+    """Built-in-generator columns of the golden inputs, both programs."""
+    g = np.load(os.path.join(GOLD, "aux_golden.npz"))
+    _cols, inputs, _valid = load_verify_golden()
+    _c, aux, err = be.aux(0, [np.ascontiguousarray(inputs[:, k, :]) for k in range(5)])
+    assert not np.asarray(err).any()
+    bad = np.argwhere(np.asarray(aux) != g["verify"])
+    assert bad.size == 0, f"{len(bad)} mismatching (aux col, sig) entries, first {bad[:5].tolist()}"
+    gi = np.load(os.path.join(GOLD, "glv_mul_golden.npz"))["inputs"]
+    _c, aux, err = be.aux(1, [np.ascontiguousarray(gi[:, k, :]) for k in range(3)])
+    assert not np.asarray(err).any()
+    assert np.array_equal(np.asarray(aux), g["glv_mul"])
+
+
+def golden_aux_schedule(name):
+    with gzip.open(os.path.join(GOLD, "aux_schedule.json.gz"), "rt") as f:
+        return [tuple(x) for x in json.load(f)[name]]
+
+
 def golden_schedule(name):
     with gzip.open(os.path.join(GOLD, f"schedule_{name}.json.gz"), "rt") as f:
         return [tuple(x) for x in json.load(f)]

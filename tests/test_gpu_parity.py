@@ -108,6 +108,49 @@ def test_verify_wide_and_tail_launches(ora, n, ld_pad):
     assert not host[:, n:].any()
 
 
+@pytest.mark.parametrize("run_iters", [1, 4, 9, 73])
+def test_verify_run_expansion_any_run_length(ora, monkeypatch, run_iters):
+    """Below 49 152 signatures the library expands op by op; force the run-walking kernels (k_expand_runs, what a
+    2^16 batch uses) on a small ragged batch, at several run lengths, for both programs."""
+    import plonky2_ecdsa_amd as p2e
+    monkeypatch.setenv("P2E_RUNS_MIN_N", "0")
+    monkeypatch.setenv("P2E_RUN_ITERS", str(run_iters))
+    n = 700                                             # two full workgroups (paired stores) + a 188-signature tail
+    sigs = p2e.synth_signatures(seed=31 + run_iters, n=n)
+    ctx = p2e.Context(device=0, host_pointers=True)
+    want, _, wflags = ora.verify(*sigs)
+    got, err, valid = ctx.ecdsa_verify_witness_batch(*sigs)[:3]
+    assert not np.asarray(err).any() and np.asarray(valid).all() and wflags.all()
+    assert np.array_equal(np.asarray(got).view(np.uint64), want)
+    rng = R.SplitMix64(900 + run_iters)
+    k = oracle_c.pack256([rng.below(R.N) for _ in range(n)])
+    want, _, _ = ora.glv_mul(sigs[3], sigs[4], k)
+    got, err, valid = ctx.glv_mul_witness_batch(sigs[3], sigs[4], k)[:3]
+    assert not np.asarray(err).any()
+    assert np.array_equal(np.asarray(got).view(np.uint64), want)
+
+
+def test_aux_matches_golden(gpu):
+    pc.check_aux_golden(gpu)
+
+
+@pytest.mark.parametrize("program", [0, 1])
+def test_aux_random_batch_ragged(gpu, ora, program):
+    """Built-in-generator columns (bool selects, bits / digits, random-access selections) derived on the GPU from its
+    own witness matrix, against the oracle's independent walk; n = 301 is not a multiple of the workgroup size."""
+    import plonky2_ecdsa_amd as p2e
+    sigs = p2e.synth_signatures(seed=55, n=301)
+    if program == 0:
+        inputs = sigs
+    else:
+        rng = R.SplitMix64(56)
+        inputs = [sigs[3], sigs[4], oracle_c.pack256([rng.below(R.N) for _ in range(301)])]
+    wcols, want, werr = ora.aux(program, inputs)
+    cols, got, err = gpu.aux(program, inputs)
+    assert not werr.any() and not err.any()
+    assert np.array_equal(cols, wcols) and np.array_equal(got, want)
+
+
 def test_cfg3_glv_mul_1024(gpu, ora):
     """BASELINE config 3: 2^10 glv_mul witness fills."""
     import plonky2_ecdsa_amd as p2e
@@ -224,6 +267,21 @@ def test_full_size_batch_properties():
     idx = torch.tensor(limb_rows[::7], device="cuda")          # every 7th limb column: 7.6k columns x 65536
     assert int((cols[idx] >> 29).ne(0).sum()) == 0
     sample = np.linspace(0, n - 1, 48).astype(np.int64)
-    want, _, _ = oracle_c.verify_witness(*[a[sample] for a in sigs])
+    want, want_aux, _, _ = oracle_c.verify_witness_aux(*[a[sample] for a in sigs])
     got = cols[:, torch.from_numpy(sample).cuda()].cpu().numpy().view(np.uint64)
     assert np.array_equal(got, want)
+    # built-in-generator columns of the same batch, padded stride, device pointers
+    ld = cols.stride(0)
+    aux_full = torch.zeros((p2e.VERIFY_AUX_COLS, n + 16), dtype=torch.int64, device="cuda")
+    aux, aerr, abad = ctx.aux_witness_batch(p2e.PROGRAM_VERIFY, dev[4], cols, n=n, ld=ld, aux=aux_full[:, :n], ld_aux=n + 16)
+    torch.cuda.synchronize()
+    assert abad == 0 and int(aerr.sum()) == 0
+    assert np.array_equal(aux_full[:, torch.from_numpy(sample).cuda()].cpu().numpy().view(np.uint64), want_aux)
+    assert int(aux_full[:, n:].ne(0).sum()) == 0
+    # size-independent properties: every bit / bool column is 0 or 1, the 66 + 73 selections are 29-bit limbs
+    items = p2e.aux_describe(p2e.PROGRAM_VERIFY)
+    k, first, ncols, _ = items[0]
+    assert k == "split4" and int((aux_full[first:first + 261] >> 1).ne(0).sum()) == 0
+    sel_rows = [r for kind, f, _n, _l in items if kind in ("fixed_base_window", "msm_digit")
+                for r in range(f + (2 if kind == "fixed_base_window" else 1), f + (2 if kind == "fixed_base_window" else 1) + 18)]
+    assert int((aux_full[torch.tensor(sel_rows[::5], device="cuda")] >> 29).ne(0).sum()) == 0

@@ -46,6 +46,48 @@ def test_schedule_matches_reference_generator_order():
     assert (c["mul"], c["inv"], c["sub"], c["add"], c["add_many"], c["glv"]) == (1087, 312, 1267, 742, 146, 1)
 
 
+def test_aux_column_map_matches_the_gadget_order():
+    """p2e_aux_describe groups the oracle's per-builder-call records into one item per window / split /
+    conditional negation: same order, same boundaries, same labels."""
+    for prog, name, total in ((p2e.PROGRAM_VERIFY, "verify", p2e.VERIFY_AUX_COLS), (p2e.PROGRAM_GLV_MUL, "glv_mul", p2e.GLV_MUL_AUX_COLS)):
+        items = p2e.aux_describe(prog)
+        fine = pc.golden_aux_schedule(name)          # (kind, first, n, label) per builder call
+        assert p2e.aux_num_cols(prog) == total == sum(n for _k, _f, n, _l in items) == sum(o[2] for o in fine)
+        starts = {o[1]: o for o in fine}
+        pos = 0
+        for kind, first, n, label in items:
+            assert first == pos and first in starts, (kind, first)
+            assert starts[first][3] == label, (label, starts[first])
+            pos += n
+        assert pos == total
+    from collections import Counter
+    c = Counter(k for k, *_ in p2e.aux_describe(0))
+    assert (c["split4"], c["split2"], c["fixed_base_window"], c["msm_digit"], c["conditional_neg"]) == (1, 2, 66, 73, 4)
+
+
+def test_aux_bodies_match_golden():
+    pc.check_aux_golden(EmuBackend())
+
+
+def test_aux_bodies_random_batch_and_limb_range_flag():
+    emu, ora = EmuBackend(), OracleBackend()
+    sigs = p2e.synth_signatures(seed=808, n=70)
+    _c, want, _e = ora.aux(0, sigs)
+    cols, got, err = emu.aux(0, sigs)
+    assert not err.any() and np.array_equal(got, want)
+    # a scalar limb >= 2^29 has no split_le_base witness: flagged, nothing else disturbed
+    cols = cols.copy()
+    u1_col = [g for g in p2e.schedule_describe(0) if g[0] == "mul"][4][2]      # after the 4 muls of curve_assert_valid
+    cols[u1_col + 3, 7] |= np.uint64(1 << 29)
+    aux = np.zeros_like(got)
+    aerr = np.zeros(70, np.uint8)
+    import ctypes as C
+    emu.L.emu_aux(C.c_int(0), sigs[4].ctypes.data_as(C.c_void_p), cols.ctypes.data_as(C.c_void_p), C.c_size_t(70),
+                  aux.ctypes.data_as(C.c_void_p), C.c_size_t(70), C.c_size_t(70), aerr.ctypes.data_as(C.c_void_p))
+    assert aerr[7] == 1 and not np.delete(aerr, 7).any()
+    assert np.array_equal(np.delete(aux, 7, axis=1), np.delete(want, 7, axis=1))
+
+
 def test_synth_signatures_restates_sign_message():
     arrs = p2e.synth_signatures(seed=9, n=4, first=2)
     for i in range(4):

@@ -25,6 +25,36 @@ def test_oracle_glv_mul_matches_golden():
     pc.check_glv_mul_golden(OracleBackend())
 
 
+def test_oracle_aux_matches_golden():
+    pc.check_aux_golden(OracleBackend())
+
+
+def test_aux_values_satisfy_their_defining_relations():
+    """The built-in generators' targets are tied to the hot-path columns by plain Goldilocks constraints
+    (mul by bool, not = 1 - b, digit = sum of bits): re-evaluate them on the Python restatement's output."""
+    sig = R.synth_signature_at(21, 3)
+    cols, aux, ok, ops = R.verify_witness_aux(*sig)
+    assert ok and len(aux) == R.NUM_VERIFY_AUX == 8959
+    kinds = [o[0] for o in ops]
+    assert kinds.count("random_access") == 66 + 73 and kinds.count("mul_by_bool") == 4 * 139 + 2 * 4
+    # 4-bit split of u1: bits recompose the limbs, digits recompose the scalar
+    bits = aux[0:261]
+    u1_limbs = [sum(b << j for j, b in enumerate(bits[29 * k:29 * k + 29])) for k in range(9)]
+    comb = aux[261:261 + 198]
+    digits = comb[2::3]
+    assert all(c == a + 4 * b for a, b, c in zip(comb[0::3], comb[1::3], digits))
+    u1 = sum(l << (29 * k) for k, l in enumerate(u1_limbs))
+    assert u1 == sum(d << (4 * t) for t, d in enumerate(digits)) and u1 < R.N
+    assert u1 == sig[0] * pow(sig[2], -1, R.N) % R.N                                  # gadgets/ecdsa.rs:40-41
+    # every conditional add: not_b = 1 - b, products are limb * bool, and exactly one side is non-zero
+    for i, (kind, first, n, _label) in enumerate(ops):
+        if kind == "not" and i + 4 < len(ops) and [o[0] for o in ops[i + 1:i + 5]] == ["mul_by_bool"] * 4:
+            not_b = aux[first]
+            xt, yt, xf, yf = [aux[o[1]:o[1] + o[2]] for o in ops[i + 1:i + 5]]
+            assert not_b in (0, 1)
+            assert (not any(xf) and not any(yf)) if not_b == 0 else (not any(xt) and not any(yt))
+
+
 def test_constants():
     c = json.load(open(os.path.join(pc.GOLD, "constants.json")))
     # Keccak digest quoted in SURVEY.md 8c and hard-coded in oracle/p2e_oracle.c + csrc/consts.hpp
@@ -56,8 +86,8 @@ def test_reference_to_digits_kat():
     # and the gadget's split (per-29-bit-limb LE bits, regrouped) is the same plain base-2^w expansion
     limbs = R.limbs_of(x % R.N, 9)
     v = R.value_of(limbs)
-    assert R.Walker.split_4(limbs) == [(v >> (4 * i)) & 15 for i in range(66)]
-    assert R.Walker.split_2(limbs[:5]) == [(R.value_of(limbs[:5]) >> (2 * i)) & 3 for i in range(73)]
+    assert R.Walker().split_4(limbs) == [(v >> (4 * i)) & 15 for i in range(66)]
+    assert R.Walker().split_2(limbs[:5]) == [(R.value_of(limbs[:5]) >> (2 * i)) & 3 for i in range(73)]
 
 
 def test_python_ref_vs_c_oracle_random_signatures():

@@ -18,18 +18,22 @@ reps = int(os.environ.get("REPS", "10"))
 
 
 def timed(fn):
+    """median wall time per call (ms).  Every call is synchronous; the median rather than the mean because the
+    runtime occasionally stalls a call of a tiny batch for ~100 ms (seen once in ~10 calls at n = 2^10)."""
+    import time
     fn()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
+    ts = []
     for _ in range(reps):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
         fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / reps
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
-which = sys.argv[1:] or ["split", "mul", "transpose", "glv"]
+which = sys.argv[1:] or ["split", "mul", "transpose", "glv", "aux"]
 if "split" in which:
     for lg in (20, 24, 26):
         n = 1 << lg
@@ -76,3 +80,19 @@ if "glv" in which:
         print(json.dumps({"kernel": "glv_mul pipeline", "n": n, "ms": round(ms, 4), "fills_per_s": round(n / ms * 1e3, 1),
                           "alg_bytes": b, "GBps": round(b / ms / 1e6, 1), "frac_hbm_peak": round(b / ms / 1e6 / PEAK, 4)}), flush=True)
         del cols
+if "aux" in which:
+    # built-in-generator columns from a finished 2^16 verify witness matrix.
+    # algorithmic bytes per signature: 8 959 columns written + the columns each item reads (4 x 9 limbs of the two
+    # selects, 1-2 digit limbs; MSM digits also gather 18 table limbs) = (66*38 + 73*58 + 60) * 8 B read
+    n = 1 << 16
+    sig = p2e.synth_signatures(seed=4, n=n)
+    dev = [torch.from_numpy(a).cuda() for a in sig]
+    ld = n + 16
+    cols = torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device="cuda")
+    ctx.ecdsa_verify_witness_batch(*dev, cols=cols[:, :n], ld=ld)
+    aux = torch.empty((p2e.VERIFY_AUX_COLS, ld), dtype=torch.int64, device="cuda")
+    err = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ms = timed(lambda: ctx.aux_witness_batch(0, dev[4], cols, n=n, ld=ld, aux=aux[:, :n], err=err, ld_aux=ld))
+    b = n * 8 * (p2e.VERIFY_AUX_COLS + 66 * 38 + 73 * 58 + 60)
+    print(json.dumps({"kernel": "k_aux", "n": n, "aux_cols": p2e.VERIFY_AUX_COLS, "ms": round(ms, 4), "alg_bytes": b,
+                      "GBps": round(b / ms / 1e6, 1), "frac_hbm_peak": round(b / ms / 1e6 / PEAK, 4)}), flush=True)

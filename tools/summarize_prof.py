@@ -41,7 +41,7 @@ out = {"source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE /
                 "of a 16 B/lane streaming read)", "kernels": {}}
 # the PMC runs use bench.py --steps 2 --warmup 1 : 3 pipeline steps, so per-step sums = total / 3
 STEPS = 3
-for k in ("k_expand", "k_batch_inv", "k_chains", "k_scalar"):
+for k in ("k_expand_runs", "k_expand", "k_batch_inv", "k_chains", "k_scalar"):
     f = fetch.get(k, [])
     w = write.get(k, [])
     if not f and not w:
@@ -51,9 +51,9 @@ for k in ("k_expand", "k_batch_inv", "k_chains", "k_scalar"):
     out["kernels"][k] = {"launches_per_step": len(f) // STEPS, "FETCH_SIZE_bytes_raw_per_step": fb,
                          "WRITE_SIZE_bytes_per_step": wb, "fetch_bytes_corrected_x2_per_step": fb * 2 if fb else None,
                          "hbm_bytes_per_step": (fb * 2 if fb else 0) + (wb or 0)}
-if "k_expand" in out["kernels"]:
-    ke = out["kernels"]["k_expand"]
-    out["hbm_bytes_per_launch_avg"] = ke["hbm_bytes_per_step"] / max(1, ke["launches_per_step"])
+# per launch, for bench.py's roofline.traffic (same "per launch" basis as roofline.achieved)
+out["hbm_bytes_per_launch"] = {k: v["hbm_bytes_per_step"] / max(1, v["launches_per_step"])
+                               for k, v in out["kernels"].items() if k.startswith("k_expand")}
 out["hbm_bytes_per_step_all_kernels"] = sum(v["hbm_bytes_per_step"] for v in out["kernels"].values())
 cal = []
 fl, wl = cal_f.get("k_split", []), cal_w.get("k_split", [])
