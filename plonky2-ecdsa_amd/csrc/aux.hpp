@@ -66,7 +66,7 @@ P2E_HD void aux_load_limbs(const AuxArgs& A, u32 src, size_t i, u64* l, int nl) 
     if (src & AUX_SRC_CONST) {
         const u32 id = src & 0xFFFFu;
         const Aff a = A.cpts[id >> 1];
-        aux_limbs_of((id & 1) ? a.y : a.x, l);
+        aux_limbs_of(u256_select((id & 1) != 0, a.y, a.x), l);   // (a struct-level ?: would live in scratch)
     } else if (src == AUX_SRC_INPUT_PY) {
         const u32* p = reinterpret_cast<const u32*>(A.py + 32 * i);
         U256 v;
@@ -98,9 +98,10 @@ P2E_HD void aux_put_select(E& e, const u64* l, int nl, u64 b) {
     for (int k = 0; k < NL; k++)
         if (k < nl) e.put(b ? l[k] : 0);
 }
-// not(b), then the four products of curve_conditional_add gadgets/curve.rs:233-238
+// not(b), then the four products of curve_conditional_add gadgets/curve.rs:233-238.  nlx, nly are literal NL on
+// the common path (only a constant p1 can be shorter), which keeps the paired-store bookkeeping compile-time.
 template <class E>
-P2E_HD void aux_put_cond_add(E& e, const AuxArgs& A, const AuxItem& it, size_t i, u64 b) {
+P2E_HD void aux_put_cond_add(E& e, const AuxArgs& A, const AuxItem& it, size_t i, u64 b, int nlx, int nly) {
     const u64 not_b = 1 - b;
     e.put(not_b);
     u64 l[NL];
@@ -108,36 +109,55 @@ P2E_HD void aux_put_cond_add(E& e, const AuxArgs& A, const AuxItem& it, size_t i
     aux_put_select(e, l, NL, b);
     aux_load_limbs(A, it.sumy, i, l, NL);
     aux_put_select(e, l, NL, b);
-    aux_load_limbs(A, it.p1x, i, l, it.nlx);
-    aux_put_select(e, l, it.nlx, not_b);
-    aux_load_limbs(A, it.p1y, i, l, it.nly);
-    aux_put_select(e, l, it.nly, not_b);
+    aux_load_limbs(A, it.p1x, i, l, nlx);
+    aux_put_select(e, l, nlx, not_b);
+    aux_load_limbs(A, it.p1y, i, l, nly);
+    aux_put_select(e, l, nly, not_b);
+}
+template <class E>
+P2E_HD void aux_put_cond_add(E& e, const AuxArgs& A, const AuxItem& it, size_t i, u64 b) {
+    if (it.nlx == NL && it.nly == NL)
+        aux_put_cond_add(e, A, it, i, b, NL, NL);
+    else
+        aux_put_cond_add(e, A, it, i, b, (int)it.nlx, (int)it.nly);
+}
+// split_nonnative_to_{4,2}_bit_limbs of a scalar with NLS limbs (gadgets/split_nonnative.rs:25-72)
+template <class E, int NLS, int WB>
+P2E_HD void aux_put_split(E& e, const AuxArgs& A, const AuxItem& it, size_t i) {
+    u64 l[NL];
+    aux_load_limbs(A, it.a, i, l, NLS);
+    bool bad = false;
+    P2E_UNROLL
+    for (int k = 0; k < NLS; k++) {
+        bad = bad || (l[k] >> BITS) != 0;   // split_le_base(limb, 29) has no witness for a wider limb
+        P2E_UNROLL
+        for (int j = 0; j < BITS; j++) e.put((l[k] >> j) & 1);
+    }
+    if (bad) err_or(&A.err[i], ERR_LIMB_RANGE);
+    constexpr int nbits = NLS * BITS;
+    P2E_UNROLL
+    for (int t = 0; WB * t < nbits; t++) {
+        // digit t from the limbs already in registers (zero padded above the last limb)
+        const int bit = WB * t, li = bit / BITS, sh = bit % BITS;
+        u32 d = (u32)(l[li] >> sh);
+        if (sh + WB > BITS && li + 1 < NLS) d |= (u32)l[li + 1] << (BITS - sh);
+        d &= (1u << WB) - 1;
+        if (WB == 4) {
+            e.put(d & 3);    // lower = mul_add(b, two, a)
+            e.put(d >> 2);   // upper = mul_add(d, two, c)
+        }
+        e.put(d);            // mul_add(upper, four, lower) / mul_add(b, two, a)
+    }
 }
 
 template <class E>
 P2E_HD void body_aux(const AuxArgs& A, int item, size_t i) {
     const AuxItem it = A.items[item];
     E e = E::at(A.aux, A.ald, i, it.aux_col);
-    if (it.kind == AUX_SPLIT4 || it.kind == AUX_SPLIT2) {
-        u64 l[NL];
-        aux_load_limbs(A, it.a, i, l, it.nlx);
-        bool bad = false;
-        for (int k = 0; k < it.nlx; k++) {
-            bad = bad || (l[k] >> BITS) != 0;   // split_le_base(limb, 29) has no witness for a wider limb
-            for (int j = 0; j < BITS; j++) e.put((l[k] >> j) & 1);
-        }
-        if (bad) err_or(&A.err[i], ERR_LIMB_RANGE);
-        const int nbits = it.nlx * BITS;
-        if (it.kind == AUX_SPLIT4) {
-            for (int t = 0; 4 * t < nbits; t++) {
-                const u32 d = aux_digit<4>(A, it.a, it.nlx, t, i);
-                e.put(d & 3);    // lower = mul_add(b, two, a)
-                e.put(d >> 2);   // upper = mul_add(d, two, c)
-                e.put(d);        // mul_add(upper, four, lower)
-            }
-        } else {
-            for (int t = 0; 2 * t < nbits; t++) e.put(aux_digit<2>(A, it.a, it.nlx, t, i));
-        }
+    if (it.kind == AUX_SPLIT4) {         // the scalar of fixed_base_curve_mul_circuit: 9 limbs
+        aux_put_split<E, NL, 4>(e, A, it, i);
+    } else if (it.kind == AUX_SPLIT2) {  // k1, k2 of the GLV decomposition: 5 limbs
+        aux_put_split<E, 5, 2>(e, A, it, i);
     } else if (it.kind == AUX_FBWIN) {   // gadgets/curve_fixed_base.rs:56-61
         const u32 d = aux_digit<4>(A, it.a, NL, (int)it.b, i);
         const u64 is_zero = d == 0, should_add = 1 - is_zero;
@@ -168,8 +188,13 @@ P2E_HD void body_aux(const AuxArgs& A, int item, size_t i) {
         u64 l[NL];
         aux_load_limbs(A, it.sumx, i, l, NL);
         aux_put_select(e, l, NL, b);
-        aux_load_limbs(A, it.p1x, i, l, it.nlx);
-        aux_put_select(e, l, it.nlx, not_b);
+        if (it.nlx == NL) {
+            aux_load_limbs(A, it.p1x, i, l, NL);
+            aux_put_select(e, l, NL, not_b);
+        } else {
+            aux_load_limbs(A, it.p1x, i, l, it.nlx);
+            aux_put_select(e, l, it.nlx, not_b);
+        }
     }
     e.flush();
 }

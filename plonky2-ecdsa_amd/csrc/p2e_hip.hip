@@ -80,9 +80,14 @@ __global__ __launch_bounds__(BS) void k_expand_runs(Program G, Buffers B, int it
     }
 }
 // built-in-generator columns from the finished witness matrix: one (signature, item) per lane (aux.hpp)
-__global__ __launch_bounds__(BS) void k_aux(AuxArgs A, int item0) {
-    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
-    if (i < A.n) body_aux<Emit>(A, item0 + (int)blockIdx.y, i);
+template <bool WIDE>
+__global__ __launch_bounds__(BS) void k_aux(AuxArgs A, size_t first) {
+    size_t i = lane_sig<WIDE>(first);
+    if (WIDE) {
+        body_aux<PairEmit>(A, (int)blockIdx.y, i);
+    } else if (i < A.n) {
+        body_aux<Emit>(A, (int)blockIdx.y, i);
+    }
 }
 // err words -> caller's err bytes, valid bytes, flagged count
 __global__ __launch_bounds__(BS) void k_finalize(const u32* err32, const uint8_t* valid8, uint8_t* err_out,
@@ -992,8 +997,13 @@ extern "C" long p2e_aux_witness_batch(p2e_ctx* c, int program, const uint8_t* pk
     u32* err32 = (u32*)c->scratch;
     HIP_TRY(hipMemsetAsync(err32, 0, n * sizeof(u32), c->stream));
     AuxArgs A{cols, ld, aux, ld_aux, n, pky32, c->d_cpts, c->d_fbtab, DP.d_aux_items, DP.d_aux_tab, err32};
-    const unsigned gx = (unsigned)((n + BS - 1) / BS);
-    hipLaunchKernelGGL(k_aux, dim3(gx, (unsigned)DP.aux_items.size()), dim3(BS), 0, c->stream, A, 0);
+    const unsigned gx = (unsigned)((n + BS - 1) / BS), items = (unsigned)DP.aux_items.size();
+    // 16-byte paired column stores for the full workgroups (PairEmit), 8-byte ones for the ragged tail
+    const bool wide_ok = (ld_aux % 2 == 0) && ((reinterpret_cast<uintptr_t>(aux) & 15) == 0) && !getenv("P2E_NARROW_STORES");
+    const size_t n_wide = wide_ok ? (n / BS) * BS : 0;
+    if (n_wide) hipLaunchKernelGGL(k_aux<true>, dim3((unsigned)(n_wide / BS), items), dim3(BS), 0, c->stream, A, (size_t)0);
+    if (n > n_wide)
+        hipLaunchKernelGGL(k_aux<false>, dim3((unsigned)((n - n_wide + BS - 1) / BS), items), dim3(BS), 0, c->stream, A, n_wide);
     hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, err32, (const uint8_t*)nullptr, err,
                        (uint8_t*)nullptr, n, c->d_counter);
     c->have_phases = false;

@@ -15,6 +15,7 @@
 //   gadgets/glv.rs:26-44          decompose_secp256k1_scalar / glv_mul
 //   gadgets/ecdsa.rs:30           verify_secp256k1_message_circuit
 #pragma once
+#include <cassert>
 #include <string>
 #include <vector>
 
@@ -102,7 +103,8 @@ public:
     // gadgets/split_nonnative.rs:25-50 / :52-72: split_le_base bits of every limb, then the digits built from them
     void split_nonnative_to_4_bit_limbs(NonNativeTarget v) {
         AuxItem it{};
-        it.kind = AUX_SPLIT4;
+        it.kind = AUX_SPLIT4;   // aux.hpp splits exactly the 9 limbs of a full scalar here ...
+        assert(v.nl == NL);
         it.a = v.col;
         it.nlx = (uint8_t)v.nl;
         const u32 nbits = (u32)v.nl * BITS;
@@ -110,7 +112,8 @@ public:
     }
     void split_nonnative_to_2_bit_limbs(NonNativeTarget v) {
         AuxItem it{};
-        it.kind = AUX_SPLIT2;
+        it.kind = AUX_SPLIT2;   // ... and the 5 limbs of a GLV half-scalar here
+        assert(v.nl == 5);
         it.a = v.col;
         it.nlx = (uint8_t)v.nl;
         const u32 nbits = (u32)v.nl * BITS;
