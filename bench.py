@@ -220,7 +220,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed
-        pmc = pmc_traffic() or {}
+        # the committed PMC summary was collected on the metric's batch (2^16 per GPU): no traffic figure otherwise
+        pmc = (pmc_traffic() or {}) if args.batch_log2 == 16 else {}
 
         def roofline(kernel, st):
             # `launches` launches per step (one per schedule segment); per launch:
