@@ -240,6 +240,15 @@ def test_api_misuse_returns_status_not_crash():
     rc = ctx._L.p2e_add_witness_batch(ctx._h, p2e.C.c_int(0), p2e._ptr(x), p2e._ptr(x), p2e._ptr(x), p2e._ptr(x),
                                       p2e.C.c_size_t(8), p2e.C.c_size_t(4), p2e._ptr(x))   # ld < n
     assert rc == -1
+    L, c = ctx._L, p2e.C
+    py, e = np.zeros((4, 32), dtype=np.uint8), np.zeros(4, dtype=np.uint8)
+    cols, aux = np.zeros((p2e.VERIFY_COLS, 4), dtype=np.uint64), np.zeros((p2e.VERIFY_AUX_COLS, 4), dtype=np.uint64)
+    ok_args = lambda prog=0, ld_aux=4, a=aux: (ctx._h, c.c_int(prog), p2e._ptr(py), p2e._ptr(cols), c.c_size_t(4), p2e._ptr(a),
+                                               c.c_size_t(ld_aux), c.c_size_t(4), p2e._ptr(e))
+    assert L.p2e_aux_witness_batch(*ok_args(prog=2)) == -1            # unknown program
+    assert L.p2e_aux_witness_batch(*ok_args(ld_aux=3)) == -1          # ld_aux < n
+    assert L.p2e_aux_witness_batch(*ok_args(a=None)) == -1            # null output
+    assert L.p2e_aux_witness_batch(*ok_args()) >= 0                   # an all-zero matrix is a valid (if meaningless) input
 
 
 def test_full_size_batch_properties():
