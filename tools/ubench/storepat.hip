@@ -36,6 +36,18 @@ __global__ __launch_bounds__(256) void k_st16x2(u64* out, size_t ld, int seg) { 
         p += ld; v += 0x1234567;
     }
 }
+// reference points: a perfectly linear fill (every wave writes 1 KB, waves walk the buffer in order), with plain and
+// with non-temporal stores
+template <bool NT>
+__global__ __launch_bounds__(256) void k_linear(uint4* out, size_t n16) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    v4u v = {(unsigned)i, 1u, 2u, 3u};
+    for (; i < n16; i += step) {
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(out + i));
+        else *reinterpret_cast<v4u*>(out + i) = v;
+    }
+}
 template <class F> float timeit(F f) {
     hipEvent_t s, e; (void)hipEventCreate(&s); (void)hipEventCreate(&e);
     f(); (void)hipDeviceSynchronize();
@@ -53,6 +65,15 @@ int main() {
         float c = timeit([&] { hipLaunchKernelGGL(k_st16x2, dim3(n / 512, segs), dim3(256), 0, 0, d, ld, 0); });
         printf("pad=%zu: 8B/lane %.3f ms %.2f TB/s | 16B paired-columns %.3f ms %.2f TB/s | 16B 2-sigs/lane %.3f ms %.2f TB/s\n", pad,
                a, bytes / a / 1e9, b, bytes / b / 1e9, c, bytes / c / 1e9);
+        size_t n16 = (size_t)segs * COLS * ld / 2;
+        for (unsigned blocks : {2048u, 8192u, 65536u}) {
+            float l0 = timeit([&] { hipLaunchKernelGGL(k_linear<false>, dim3(blocks), dim3(256), 0, 0, (uint4*)d, n16); });
+            float l1 = timeit([&] { hipLaunchKernelGGL(k_linear<true>, dim3(blocks), dim3(256), 0, 0, (uint4*)d, n16); });
+            printf("   linear fill, %u blocks: plain %.3f ms %.2f TB/s | nt %.3f ms %.2f TB/s\n", blocks, l0, n16 * 16.0 / l0 / 1e9, l1,
+                   n16 * 16.0 / l1 / 1e9);
+        }
+        float m = timeit([&] { (void)hipMemsetAsync(d, 0x5a, n16 * 16, 0); });
+        printf("   hipMemsetAsync %.3f ms %.2f TB/s\n", m, n16 * 16.0 / m / 1e9);
         (void)hipFree(d);
     }
     return 0;
