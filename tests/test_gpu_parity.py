@@ -163,7 +163,16 @@ def test_cfg3_glv_mul_1024(gpu, ora):
     assert np.array_equal(np.asarray(got).view(np.uint64), want)
 
 
-def test_edge_inputs_and_error_flags(gpu, ora):
+@pytest.mark.parametrize("runs", [False, True], ids=["op_by_op", "run_expansion"])
+def test_edge_inputs_and_error_flags(gpu, ora, monkeypatch, runs):
+    if runs:   # the expansion a 2^16 batch uses (k_expand_runs), forced on this small batch
+        import plonky2_ecdsa_amd as p2e
+        monkeypatch.setenv("P2E_RUNS_MIN_N", "0")
+
+        class _G:
+            ctx = p2e.Context(device=0, host_pointers=True)
+            verify = lambda self, *a: self.ctx.ecdsa_verify_witness_batch(*[np.ascontiguousarray(x, np.uint8) for x in a])[:3]
+        gpu = _G()
     sig = list(R.synth_signature_at(5, 0))
     rx, ry = R.rando_point()
     cases = [tuple(sig)]
