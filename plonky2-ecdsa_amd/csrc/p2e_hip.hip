@@ -52,10 +52,16 @@ __global__ __launch_bounds__(BS) void k_chains(Program G, Buffers B, int lo, int
     size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
     if (i < B.n) body_chain_range(G, B, i, lo, hi, table_affine != 0, continue_prefix != 0);
 }
-// one inversion batch: ops [lo, hi), whose prefix products phase A has already left in PREF
-__global__ __launch_bounds__(BS) void k_batch_inv(Program G, Buffers B, int lo, int hi) {
+// independent interleaved sub-chains of a piece, one per blockIdx.y (the MSM window table)
+__global__ __launch_bounds__(BS) void k_chain_rows(Program G, Buffers B, int lo, int count) {
+    __builtin_amdgcn_s_setprio(3);
     size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
-    if (i < B.n) body_batch_inv(G, B, i, lo, hi, true);
+    if (i < B.n) body_chain_rows(G, B, i, lo, (int)gridDim.y, (int)blockIdx.y, count);
+}
+// one inversion batch: ops [lo, hi); have_prefix: phase A has already left its prefix products in PREF
+__global__ __launch_bounds__(BS) void k_batch_inv(Program G, Buffers B, int lo, int hi, int have_prefix) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    if (i < B.n) body_batch_inv(G, B, i, lo, hi, have_prefix != 0);
 }
 // op lo + blockIdx.y
 template <bool WIDE>
@@ -871,7 +877,17 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         Seg& sg = segs[k];
         // once the table piece has been inverted on this stream (below), later pieces read the table affine
         const int table_affine = (sg.chain_stream == c->st_msm && k > first_msm) ? 1 : 0;
-        hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, sg.hi, table_affine, 0);
+        // glv_mul alone: the window table as 2 chains of 4 adds, then 6 and 9 independent adds (body_chain_rows):
+        // -6 % at 2^10, -4 % at 2^16.  Not in the verify program: there the fixed-base chain runs beside it, three
+        // 186-VGPR waves do not fit a SIMD and the rows only queue (+0.6...1 % measured).
+        const bool table_rows = !verify && k == first_msm && sg.hi - sg.lo == MSM_TABLE_OPS;
+        if (table_rows) {
+            hipLaunchKernelGGL(k_chain_rows, dim3(gx, 2), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, 4);
+            hipLaunchKernelGGL(k_chain_rows, dim3(gx, 6), dim3(BS), 0, sg.chain_stream, G, B, sg.lo + 8, 1);
+            hipLaunchKernelGGL(k_chain_rows, dim3(gx, 9), dim3(BS), 0, sg.chain_stream, G, B, sg.lo + 14, 1);
+        } else {
+            hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, sg.hi, table_affine, 0);
+        }
         if (verify && k == first_msm - 1) HIP_TRY(hipEventRecord(c->ev_fixed, c->st_fixed));
         if (sg.final_after) {
             HIP_TRY(hipStreamWaitEvent(c->st_msm, c->ev_fixed, 0));
@@ -886,7 +902,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             // stream (the rest of the chain is not on the critical path: it ends long before the expansion
             // does), so that the first k_expand can start ~0.8 ms earlier than if it queued behind the
             // fixed-base chain on the other stream.
-            hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, c->st_msm, G, B, sg.lo, sg.hi);
+            hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, c->st_msm, G, B, sg.lo, sg.hi, table_rows ? 0 : 1);
             HIP_TRY(hipEventRecord(c->ev_binv[k], c->st_msm));
         }
     }
@@ -909,7 +925,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         hipStream_t st_b = c->st_fixed;
         if (k != first_msm) {
             HIP_TRY(hipStreamWaitEvent(st_b, c->ev_piece[k], 0));
-            hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, st_b, G, B, sg.lo, sg.hi);
+            hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, st_b, G, B, sg.lo, sg.hi, 1);
             HIP_TRY(hipEventRecord(c->ev_binv[k], st_b));
         }
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_binv[k], 0));

@@ -39,6 +39,7 @@ struct OpDesc {
 };
 constexpr int CONST_RANDO = 0, CONST_NEG_RANDO = 1, CONST_NEG_RANDO_146 = 2, NUM_CONST_PTS = 3;
 constexpr int FB_WINDOWS = 66, MSM_DIGITS = 73;
+constexpr int MSM_TABLE_OPS = 23;  // curve_msm_circuit's precomputation: 8 + 6 + 9 adds (gadgets/curve_msm.rs:45-60)
 constexpr int COLS_ADD = 231, COLS_DBL = 282, COLS_CADD = 251;
 
 // column anchors of the non-curve-op part of the schedule (filled by the host walk)
@@ -352,6 +353,19 @@ P2E_HD void body_chain_range(const Program& G, const Buffers& B, size_t i, int l
     st.out.X = st.out.Y = st.out.Z = st.p1.X = st.p1.Y = st.p1.Z = u256_zero();
     st.acc = continue_prefix ? range_product(B, i, lo - 1) : u256_small(1);
     for (int t = lo; t < hi; t++) body_chain_op(G, B, i, t, table_affine, st);
+}
+
+// Ops lo + row + j * rows (j < count) of a piece whose `rows` interleaved sub-chains do not depend on each other.
+// The MSM window table (gadgets/curve_msm.rs:45-60, 23 ops) is such a piece three times over: the two 4-op chains
+// rando + i*p / rando + i*q (rows = 2, count = 4), the 6 adds that strip rando and the 9 cross sums (one op per
+// row).  Walking the rows with different lanes shortens the latency-bound start of every call from 23 dependent
+// ops to 6.  The prefix products of the piece's inversion batch are then left to phase B (have_prefix = false).
+P2E_HD void body_chain_rows(const Program& G, const Buffers& B, size_t i, int lo, int rows, int row, int count) {
+    ChainState st;
+    st.out_id = st.p1_id = 0xFFFF;
+    st.out.X = st.out.Y = st.out.Z = st.p1.X = st.p1.Y = st.p1.Z = u256_zero();
+    st.acc = u256_small(1);
+    for (int j = 0; j < count; j++) body_chain_op(G, B, i, lo + row + j * rows, false, st);
 }
 
 // ---- phase B: Montgomery batch inversion of Z over ops [t0, t1) of one signature ------------------------

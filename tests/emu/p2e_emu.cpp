@@ -82,8 +82,23 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     {
         const int lo0 = G.chain_begin[0], hi0 = G.chain_end[0], lb = G.msm_loop_begin, iters = G.msm_loop_iters;
         const int le = lb + 3 * iters, R = run_iters > 0 ? run_iters : 1, groups = 3;
-        chain(lo0, lb, false);
-        binv(lo0, lb);
+        if (G.num_chains == 1) {
+            // glv_mul alone: the window table as rows of independent sub-chains, as the GPU walks it there
+            // (body_chain_rows), prefix products left to phase B
+            auto rows = [&](int lo, int nrows, int count) {
+#pragma omp parallel for
+                for (long long i = 0; i < (long long)n; i++)
+                    for (int r = 0; r < nrows; r++) body_chain_rows(G, B, (size_t)i, lo, nrows, r, count);
+            };
+            rows(lo0, 2, 4);
+            rows(lo0 + 8, 6, 1);
+            rows(lo0 + 14, 9, 1);
+#pragma omp parallel for
+            for (long long i = 0; i < (long long)n; i++) body_batch_inv(G, B, (size_t)i, lo0, lb, false);
+        } else {
+            chain(lo0, lb, false);
+            binv(lo0, lb);
+        }
         expand(lo0, lb);
         const int nruns = (iters + R - 1) / R;
         int rn = 0;
