@@ -66,7 +66,9 @@ typedef struct p2e_ctx p2e_ctx;
 /* ---- context ------------------------------------------------------------------------------------ */
 /* `stream`: a hipStream_t to run on (e.g. torch's current stream), or NULL for a library-owned one.  The
  * library-owned stream is a blocking stream (hipStreamDefault): work the caller queued on the legacy default
- * stream before a call is ordered before it, and default-stream work queued after a call is ordered after it. */
+ * stream before a call is ordered before it, and default-stream work queued after a call is ordered after it.
+ * The fused entry points use two more internal streams; export GPU_MAX_HW_QUEUES=8 before the process's first
+ * HIP call so that they do not share a hardware queue with the caller's streams. */
 int p2e_ctx_create(int device, unsigned flags, void *stream, p2e_ctx **out);
 void p2e_ctx_destroy(p2e_ctx *ctx);
 int p2e_sync(p2e_ctx *ctx);
