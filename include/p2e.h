@@ -160,6 +160,19 @@ long p2e_aux_num_cols(int program);
 long p2e_columns_to_rows(p2e_ctx *ctx, const uint64_t *cols, size_t ld, size_t n, size_t ncols, uint64_t *rows,
                          size_t row_ld);
 
+/* Compact container for transfers (BASELINE config 5 is bound by the host link, not by the GPU): 57 % of the
+ * columns only ever hold values < 2^32 (29-bit limbs, overflow words, flags; set through set_ux_target /
+ * set_bool_target in the reference, gadgets/nonnative.rs:643-644,726-727) and are repacked as u32 narrow[num_narrow][ld_narrow];
+ * the check_sum[17] and b[16] columns of every mul generator (gates/mul_nonnative.rs:305-322,518-527) stay u64
+ * wide[num_wide][ld_wide]: 474 KB instead of 661 KB per verify.  col_map[c] (p2e_compact_layout, host only) is the
+ * index of witness column c inside its matrix, with P2E_COMPACT_WIDE set for the wide one.  err[i] gets
+ * P2E_ERR_LIMB_RANGE if a narrow column of signature i holds a value >= 2^32 (cannot happen for this library's
+ * own output). */
+#define P2E_COMPACT_WIDE 0x80000000u
+long p2e_compact_layout(int program, uint32_t *col_map, size_t cap, uint32_t *num_narrow, uint32_t *num_wide);
+long p2e_columns_compact(p2e_ctx *ctx, int program, const uint64_t *cols, size_t ld, size_t n, uint32_t *narrow,
+                         size_t ld_narrow, uint64_t *wide, size_t ld_wide, uint8_t *err);
+
 /* ---- schedule description (column -> generator map, host only, no GPU needed) ---------------------- */
 typedef struct p2e_gen_desc {
     int32_t kind;  /* 0 add, 1 sub, 2 add_many, 3 mul(+checksum), 4 inv, 5 glv_decomposition */

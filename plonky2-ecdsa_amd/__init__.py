@@ -48,6 +48,7 @@ EXPORTS = (
     "p2e_limb_pack", "p2e_ecdsa_verify_witness_batch", "p2e_glv_mul_witness_batch", "p2e_columns_to_rows",
     "p2e_schedule_describe",
     "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
+    "p2e_compact_layout", "p2e_columns_compact",
 )
 
 
@@ -100,7 +101,8 @@ def lib():
         _lib.p2e_scratch_bytes.argtypes = [C.c_int, C.c_size_t]
         for name in EXPORTS:
             if name.endswith("_batch") or name in ("p2e_limb_split", "p2e_limb_pack", "p2e_columns_to_rows", "p2e_schedule_describe",
-                                                   "p2e_schedule_num_cols", "p2e_aux_describe", "p2e_aux_num_cols"):
+                                                   "p2e_schedule_num_cols", "p2e_aux_describe", "p2e_aux_num_cols", "p2e_compact_layout",
+                                                   "p2e_columns_compact"):
                 getattr(_lib, name).restype = C.c_long
     return _lib
 
@@ -140,6 +142,30 @@ def aux_describe(program: int = PROGRAM_VERIFY):
     L.p2e_aux_describe(C.c_int(program), arr, C.c_size_t(n))
     kinds = ("split4", "split2", "fixed_base_window", "msm_digit", "conditional_neg")
     return [(kinds[d.kind], d.first_col, d.num_cols, d.label.decode()) for d in arr]
+
+
+COMPACT_WIDE = 0x80000000
+
+
+def compact_layout(program: int = PROGRAM_VERIFY):
+    """(col_map, num_narrow, num_wide) of the compact transfer container (include/p2e.h p2e_columns_compact):
+    col_map[c] = index of witness column c in the u32 narrow matrix, or COMPACT_WIDE | index in the u64 wide one."""
+    L = lib()
+    ncols = schedule_num_cols(program)
+    m = np.zeros(ncols, dtype=np.uint32)
+    nn, nw = C.c_uint32(), C.c_uint32()
+    L.p2e_compact_layout(C.c_int(program), _ptr(m), C.c_size_t(ncols), C.byref(nn), C.byref(nw))
+    return m, int(nn.value), int(nw.value)
+
+
+def compact_expand(program, narrow, wide):
+    """Host-side inverse of Context.columns_compact (numpy): the (num_cols, n) u64 matrix."""
+    m, nn, nw = compact_layout(program)
+    out = np.empty((len(m), narrow.shape[1]), dtype=np.uint64)
+    is_wide = (m & COMPACT_WIDE) != 0
+    out[~is_wide] = np.asarray(narrow)[m[~is_wide]]
+    out[is_wide] = np.asarray(wide).view(np.uint64)[m[is_wide] & 0x7FFFFFFF]
+    return out
 
 
 def aux_num_cols(program: int = PROGRAM_VERIFY) -> int:
@@ -334,6 +360,26 @@ class Context:
         bad = self._check(self._L.p2e_aux_witness_batch(self._h, C.c_int(program), _ptr(pky), _ptr(cols), C.c_size_t(ld),
                                                         _ptr(aux), C.c_size_t(ld_aux), C.c_size_t(n), _ptr(err)))
         return aux, err, bad
+
+    def columns_compact(self, program, cols, n=None, ld=None, narrow=None, wide=None, err=None, ld_narrow=None, ld_wide=None):
+        """Repack a finished witness matrix for transfers: (narrow u32 (num_narrow, n), wide u64 (num_wide, n), err, bad).
+        Preallocated `narrow` / `wide` may be column slices of wider matrices: pass their row strides."""
+        _m, nn, nw = compact_layout(program)
+        ld = ld if ld is not None else self._shape(cols)[1]
+        n = n if n is not None else self._shape(cols)[1]
+        if narrow is None or wide is None:
+            if self.host_pointers:
+                narrow, wide = np.zeros((nn, n), dtype=np.uint32), np.zeros((nw, n), dtype=np.uint64)
+            else:
+                import torch
+                dev = f"cuda:{self.device}"
+                narrow = torch.empty((nn, n), dtype=torch.int32, device=dev)
+                wide = torch.empty((nw, n), dtype=torch.int64, device=dev)
+        err = err if err is not None else self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_columns_compact(self._h, C.c_int(program), _ptr(cols), C.c_size_t(ld), C.c_size_t(n),
+                                                      _ptr(narrow), C.c_size_t(ld_narrow or self._shape(narrow)[1]), _ptr(wide),
+                                                      C.c_size_t(ld_wide or self._shape(wide)[1]), _ptr(err)))
+        return narrow, wide, err, bad
 
     def glv_mul_witness_batch(self, px, py, k, cols=None, err=None, valid=None, ld=None):
         """glv_mul (gadgets/glv.rs:87-104): (65243, n) Goldilocks columns."""

@@ -243,6 +243,60 @@ __global__ __launch_bounds__(BS) void k_transpose(const u64* __restrict__ cols, 
     }
 }
 
+// Compact container for transfers (p2e_columns_compact): every column whose values are < 2^32 by construction
+// (29-bit limbs, overflow words, flags: 57 % of the columns) is repacked as u32, the check_sum / carry columns of
+// the mul generators stay u64.  map[c] = index of column c in its matrix | P2E_COMPACT_WIDE.  One lane moves two
+// adjacent signatures (16-byte loads, 8- or 16-byte stores); blockIdx.y walks groups of 32 columns.
+constexpr u32 COMPACT_WIDE = 0x80000000u;
+constexpr int COMPACT_GROUP = 32;
+__global__ __launch_bounds__(BS) void k_compact(const u64* __restrict__ cols, size_t ld, size_t n, u32 ncols,
+                                                const u32* __restrict__ map, u32* __restrict__ narrow, size_t ldn,
+                                                u64* __restrict__ wide, size_t ldw, u32* err32, int pair_ok) {
+    const size_t i = ((size_t)blockIdx.x * BS + threadIdx.x) * 2;
+    if (i >= n) return;
+    const bool two = pair_ok && i + 1 < n;
+    const u32 c0 = blockIdx.y * COMPACT_GROUP;
+    u32 bad = 0;
+#pragma unroll 4
+    for (u32 k = 0; k < COMPACT_GROUP; k++) {
+        const u32 c = c0 + k;
+        if (c >= ncols) break;
+        const u32 m = map[c];
+        const u64* src = cols + (size_t)c * ld + i;
+        u64 a, b = 0;
+        if (two) {
+            const uint4 v = *reinterpret_cast<const uint4*>(src);
+            a = (u64)v.x | ((u64)v.y << 32);
+            b = (u64)v.z | ((u64)v.w << 32);
+        } else {
+            a = src[0];
+            if (i + 1 < n) b = src[1];
+        }
+        if (m & COMPACT_WIDE) {
+            u64* dst = wide + (size_t)(m & ~COMPACT_WIDE) * ldw + i;
+            if (two) {
+                *reinterpret_cast<uint4*>(dst) = make_uint4((u32)a, (u32)(a >> 32), (u32)b, (u32)(b >> 32));
+            } else {
+                dst[0] = a;
+                if (i + 1 < n) dst[1] = b;
+            }
+        } else {
+            bad |= (u32)(a >> 32) | (u32)(b >> 32);
+            u32* dst = narrow + (size_t)m * ldn + i;
+            if (two) {
+                *reinterpret_cast<uint2*>(dst) = make_uint2((u32)a, (u32)b);
+            } else {
+                dst[0] = (u32)a;
+                if (i + 1 < n) dst[1] = (u32)b;
+            }
+        }
+    }
+    if (bad) {   // a value that does not fit its 32-bit slot: flag both signatures of the lane
+        atomicOr(&err32[i], (u32)ERR_LIMB_RANGE);
+        if (i + 1 < n) atomicOr(&err32[i + 1], (u32)ERR_LIMB_RANGE);
+    }
+}
+
 // ====================================================================================================
 // context
 // ====================================================================================================
@@ -269,6 +323,10 @@ struct DeviceProgram {
     AuxTables aux_tab{};
     AuxItem* d_aux_items = nullptr;
     AuxTables* d_aux_tab = nullptr;
+    // compact container (p2e_columns_compact): per-column slot, narrow / wide column counts
+    std::vector<u32> compact_map;
+    u32 num_narrow = 0, num_wide = 0;
+    u32* d_compact_map = nullptr;
 };
 
 struct p2e_ctx {
@@ -307,6 +365,16 @@ struct p2e_ctx {
     bool have_phases = false;
 };
 
+// wide = the 33 check_sum / carry columns of every mul generator (Goldilocks residues of signed sums, carries offset
+// by 2^33: gates/mul_nonnative.rs:305-322,518-527); everything else on the path is < 2^32 by construction
+static void build_compact_map(DeviceProgram& P) {
+    P.compact_map.assign((size_t)P.prog.num_cols, 0);
+    for (const auto& g : P.gens)
+        for (u32 k = 0; k < g.ncols; k++) {
+            const bool wide = g.kind == host::GEN_MUL && k >= 2 * NL;
+            P.compact_map[g.col + k] = wide ? (COMPACT_WIDE | P.num_wide++) : P.num_narrow++;
+        }
+}
 static const DeviceProgram& host_program(int program) {
     static DeviceProgram P[2];
     static std::once_flag once;
@@ -318,6 +386,7 @@ static const DeviceProgram& host_program(int program) {
         P[0].aux_items = b0.aux_items;
         P[0].aux_gens = b0.aux_gens;
         P[0].aux_tab = b0.aux_tab;
+        build_compact_map(P[0]);
         host::ScheduleBuilder b1;
         b1.glv_mul_circuit();
         P[1].prog = b1.prog;
@@ -325,6 +394,7 @@ static const DeviceProgram& host_program(int program) {
         P[1].aux_items = b1.aux_items;
         P[1].aux_gens = b1.aux_gens;
         P[1].aux_tab = b1.aux_tab;
+        build_compact_map(P[1]);
     });
     return P[program];
 }
@@ -420,6 +490,10 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         HIP_TRY(hipMemcpy(c->progs[p].d_aux_items, HP.aux_items.data(), sizeof(AuxItem) * HP.aux_items.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc(&c->progs[p].d_aux_tab, sizeof(AuxTables)));
         HIP_TRY(hipMemcpy(c->progs[p].d_aux_tab, &HP.aux_tab, sizeof(AuxTables), hipMemcpyHostToDevice));
+        c->progs[p].num_narrow = HP.num_narrow;
+        c->progs[p].num_wide = HP.num_wide;
+        HIP_TRY(hipMalloc(&c->progs[p].d_compact_map, sizeof(u32) * HP.compact_map.size()));
+        HIP_TRY(hipMemcpy(c->progs[p].d_compact_map, HP.compact_map.data(), sizeof(u32) * HP.compact_map.size(), hipMemcpyHostToDevice));
         std::vector<OpDesc> plain = host_ops(p, 0);
         HIP_TRY(hipMalloc(&c->progs[p].d_ops_plain, sizeof(OpDesc) * plain.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_ops_plain, plain.data(), sizeof(OpDesc) * plain.size(), hipMemcpyHostToDevice));
@@ -460,6 +534,7 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
         (void)hipFree(p.d_ops_plain);
         (void)hipFree(p.d_aux_items);
         (void)hipFree(p.d_aux_tab);
+        (void)hipFree(p.d_compact_map);
     }
     (void)hipFree(c->scratch);
     (void)hipFree(c->d_counter);
@@ -994,6 +1069,36 @@ extern "C" long p2e_columns_to_rows(p2e_ctx* c, const uint64_t* cols, size_t ld,
     return S.done(finish_call(c));
 }
 
+extern "C" long p2e_columns_compact(p2e_ctx* c, int program, const uint64_t* cols, size_t ld, size_t n, uint32_t* narrow,
+                                    size_t ld_narrow, uint64_t* wide, size_t ld_wide, uint8_t* err) {
+    if (bad_common(c, n, ld) || program < 0 || program > 1 || !cols || !narrow || !wide || !err || ld_narrow < n || ld_wide < n) {
+        if (c && (ld_narrow < n || ld_wide < n)) set_error("ld_narrow / ld_wide < n");
+        return P2E_E_INVALID;
+    }
+    if (n == 0) return 0;
+    const DeviceProgram& DP = c->progs[program];
+    Staged S(c);
+    cols = S.in(cols, (size_t)DP.prog.num_cols * ld * 8);
+    narrow = S.out(narrow, (size_t)DP.num_narrow * ld_narrow * 4);
+    wide = S.out(wide, (size_t)DP.num_wide * ld_wide * 8);
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    if (int rc = ensure_scratch(c, n * sizeof(u32))) return S.done(rc);
+    ZERO_COUNTER(c);
+    u32* err32 = (u32*)c->scratch;
+    HIP_TRY(hipMemsetAsync(err32, 0, n * sizeof(u32), c->stream));
+    const int pair_ok = ld % 2 == 0 && ld_narrow % 2 == 0 && ld_wide % 2 == 0 && (reinterpret_cast<uintptr_t>(cols) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(narrow) & 7) == 0 && (reinterpret_cast<uintptr_t>(wide) & 15) == 0;
+    const u32 ncols = (u32)DP.prog.num_cols;
+    dim3 grid((unsigned)((n + 2 * BS - 1) / (2 * BS)), (ncols + COMPACT_GROUP - 1) / COMPACT_GROUP);
+    hipLaunchKernelGGL(k_compact, grid, dim3(BS), 0, c->stream, cols, ld, n, ncols, DP.d_compact_map, narrow, ld_narrow, wide,
+                       ld_wide, err32, pair_ok);
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n + BS - 1) / BS)), dim3(BS), 0, c->stream, err32, (const uint8_t*)nullptr,
+                       err, (uint8_t*)nullptr, n, c->d_counter);
+    c->have_phases = false;
+    return S.done(finish_call(c));
+}
+
 extern "C" long p2e_aux_witness_batch(p2e_ctx* c, int program, const uint8_t* pky32, const uint64_t* cols, size_t ld,
                                       uint64_t* aux, size_t ld_aux, size_t n, uint8_t* err) {
     if (bad_common(c, n, ld) || program < 0 || program > 1 || !pky32 || !cols || !aux || !err || ld_aux < n) {
@@ -1040,6 +1145,14 @@ extern "C" long p2e_aux_describe(int program, p2e_aux_desc* out, size_t cap) {
         std::strncpy(out[i].label, g[i].label.c_str(), sizeof(out[i].label) - 1);
     }
     return (long)g.size();
+}
+extern "C" long p2e_compact_layout(int program, uint32_t* col_map, size_t cap, uint32_t* num_narrow, uint32_t* num_wide) {
+    if (program < 0 || program > 1) return P2E_E_INVALID;
+    const DeviceProgram& P = host_program(program);
+    for (size_t i = 0; i < P.compact_map.size() && i < cap && col_map; i++) col_map[i] = P.compact_map[i];
+    if (num_narrow) *num_narrow = P.num_narrow;
+    if (num_wide) *num_wide = P.num_wide;
+    return (long)P.compact_map.size();
 }
 extern "C" long p2e_aux_num_cols(int program) {
     if (program < 0 || program > 1) return P2E_E_INVALID;

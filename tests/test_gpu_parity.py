@@ -239,6 +239,34 @@ def test_columns_to_rows(gpu):
     assert torch.equal(rows, cols.t())
 
 
+@pytest.mark.parametrize("n,pad", [(600, 0), (601, 0), (512, 1)])
+def test_columns_compact_round_trip(n, pad):
+    """Compact transfer container (u32 narrow + u64 wide matrices): expanding it on the host gives the witness matrix
+    back; odd batch sizes / odd strides take the single-element path; a value that does not fit is flagged."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    sigs = p2e.synth_signatures(seed=61, n=n)
+    ctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    ld = n + pad
+    big = torch.zeros((p2e.VERIFY_COLS, ld), dtype=torch.int64, device="cuda")
+    cols, err, valid, bad = ctx.ecdsa_verify_witness_batch(*dev, cols=big[:, :n], ld=ld)
+    assert bad == 0
+    _m, nn, nw = p2e.compact_layout(0)
+    nar = torch.full((nn, n + 2 * pad), -1, dtype=torch.int32, device="cuda")
+    wid = torch.full((nw, n + 4 * pad), -1, dtype=torch.int64, device="cuda")
+    _, _, cerr, cbad = ctx.columns_compact(0, big, n=n, ld=ld, narrow=nar, wide=wid, ld_narrow=n + 2 * pad, ld_wide=n + 4 * pad)
+    torch.cuda.synchronize()
+    assert cbad == 0 and int(cerr.sum()) == 0
+    back = p2e.compact_expand(0, nar[:, :n].cpu().numpy().view(np.uint32), wid[:, :n].cpu().numpy())
+    assert np.array_equal(back, big[:, :n].cpu().numpy().view(np.uint64))
+    assert bool((nar[:, n:] == -1).all()) and bool((wid[:, n:] == -1).all())       # padding untouched
+    big[7, 5] = 1 << 32                                                             # r limb of the first mul: narrow
+    _, _, cerr, cbad = ctx.columns_compact(0, big, n=n, ld=ld, narrow=nar, wide=wid, ld_narrow=n + 2 * pad, ld_wide=n + 4 * pad)
+    flagged = np.nonzero(cerr.cpu().numpy())[0].tolist()
+    assert cbad == len(flagged) and 5 in flagged and set(flagged) <= {4, 5}
+
+
 def test_api_misuse_returns_status_not_crash():
     import plonky2_ecdsa_amd as p2e
     ctx = p2e.Context(device=0, host_pointers=True)

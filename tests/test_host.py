@@ -88,6 +88,22 @@ def test_aux_bodies_random_batch_and_limb_range_flag():
     assert np.array_equal(np.delete(aux, 7, axis=1), np.delete(want, 7, axis=1))
 
 
+def test_compact_layout_is_a_partition_of_the_columns():
+    """Narrow = every column but check_sum[17] and b[16] of the mul generators; each matrix index used exactly once."""
+    for prog, muls in ((p2e.PROGRAM_VERIFY, 1087), (p2e.PROGRAM_GLV_MUL, 877)):
+        m, nn, nw = p2e.compact_layout(prog)
+        wide = (m & p2e.COMPACT_WIDE) != 0
+        assert nw == 33 * muls == int(wide.sum()) and nn == len(m) - nw
+        assert sorted((m[wide] & 0x7FFFFFFF).tolist()) == list(range(nw)) and sorted(m[~wide].tolist()) == list(range(nn))
+        for kind, _field, c0, nc, _label in p2e.schedule_describe(prog):
+            assert wide[c0:c0 + nc].tolist() == ([False] * 18 + [True] * 33 if kind == "mul" else [False] * nc)
+    assert p2e.compact_layout(0)[1:] == (46744, 35871)
+    # the goldens really fit: every narrow column of the golden witnesses is < 2^32
+    cols, _inputs, _valid = pc.load_verify_golden()
+    m, _, _ = p2e.compact_layout(0)
+    assert int((cols[(m & p2e.COMPACT_WIDE) == 0] >> np.uint64(32)).max()) == 0
+
+
 def test_synth_signatures_restates_sign_message():
     arrs = p2e.synth_signatures(seed=9, n=4, first=2)
     for i in range(4):

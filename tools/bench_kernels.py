@@ -33,7 +33,7 @@ def timed(fn):
     return ts[len(ts) // 2]
 
 
-which = sys.argv[1:] or ["split", "mul", "transpose", "glv", "aux"]
+which = sys.argv[1:] or ["split", "mul", "transpose", "glv", "aux", "compact"]
 if "split" in which:
     for lg in (20, 24, 26):
         n = 1 << lg
@@ -96,3 +96,16 @@ if "aux" in which:
     b = n * 8 * (p2e.VERIFY_AUX_COLS + 66 * 38 + 73 * 58 + 60)
     print(json.dumps({"kernel": "k_aux", "n": n, "aux_cols": p2e.VERIFY_AUX_COLS, "ms": round(ms, 4), "alg_bytes": b,
                       "GBps": round(b / ms / 1e6, 1), "frac_hbm_peak": round(b / ms / 1e6 / PEAK, 4)}), flush=True)
+if "compact" in which:
+    # compact transfer container: 661 KB read + 474 KB written per signature
+    n = 1 << 15
+    _m, nn, nw = p2e.compact_layout(0)
+    ld = n + 16
+    cols = torch.randint(0, 1 << 29, (p2e.VERIFY_COLS, ld), dtype=torch.int64, device="cuda")
+    nar = torch.empty((nn, ld), dtype=torch.int32, device="cuda")
+    wid = torch.empty((nw, ld), dtype=torch.int64, device="cuda")
+    err = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ms = timed(lambda: ctx.columns_compact(0, cols, n=n, ld=ld, narrow=nar, wide=wid, err=err, ld_narrow=ld, ld_wide=ld))
+    b = n * (p2e.VERIFY_COLS * 8 + nn * 4 + nw * 8)
+    print(json.dumps({"kernel": "k_compact", "n": n, "ms": round(ms, 4), "alg_bytes": b, "GBps": round(b / ms / 1e6, 1),
+                      "frac_hbm_peak": round(b / ms / 1e6 / PEAK, 4)}), flush=True)
