@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--allgather-cols", type=int, default=0,
                     help="N>1 only: after the timed region, all-gather this many columns over RCCL and report GB/s")
     ap.add_argument("--ld-pad", type=int, default=16, help="column stride = batch + this many elements")
+    ap.add_argument("--compact", action="store_true",
+                    help="NOT the headline: write the compact container (u32 limb/flag columns + u64 check_sum/carry columns, "
+                         "include/p2e.h) instead of the u64 column matrix; same values, 474 KB instead of 661 KB per fill")
     ap.add_argument("--pipeline-depth", type=int, default=1,
                     help="batches in flight per GPU: D > 1 issues step i on context/stream/output buffer i % D "
                          "(asynchronous C ABI), so the scalar phase and first chain pieces of the next batch "
@@ -143,8 +146,15 @@ def main():
     # column stride: n + 16 elements.  A power-of-two stride (2^16 * 8 B = 512 KiB) makes consecutive columns
     # camp on the same HBM channels (measured -9 % on k_expand); ld is part of the C ABI (ld >= n).
     ld = n + args.ld_pad
-    cols_bufs = [torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device=dev) for _ in range(depth)]
-    cols = cols_bufs[0][:, :n]
+    if args.compact:
+        _m, NN, NW = p2e.compact_layout(0)
+        nar_bufs = [torch.empty((NN, ld), dtype=torch.int32, device=dev) for _ in range(depth)]
+        wid_bufs = [torch.empty((NW, ld), dtype=torch.int64, device=dev) for _ in range(depth)]
+        cols_bufs = [None] * depth
+        cols = None
+    else:
+        cols_bufs = [torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device=dev) for _ in range(depth)]
+        cols = cols_bufs[0][:, :n]
     errs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(depth)]
     valids = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(depth)]
     err, valid = errs[0], valids[0]
@@ -155,6 +165,9 @@ def main():
         issued[0] += 1
         if depth > 1 and issued[0] > depth:
             ctxs[k].sync()                     # the batch issued `depth` steps ago on this context is done
+        if args.compact:
+            return ctxs[k].ecdsa_verify_witness_compact_batch(*inputs, narrow=nar_bufs[k], wide=wid_bufs[k], err=errs[k],
+                                                              valid=valids[k], ld_narrow=ld, ld_wide=ld)[4]
         return ctxs[k].ecdsa_verify_witness_batch(*inputs, cols=cols_bufs[k][:, :n], err=errs[k], valid=valids[k], ld=ld)[3]
 
     def drain():
@@ -205,7 +218,7 @@ def main():
         elapsed = float(t.item())
 
     gather = None
-    if world > 1 and args.allgather_cols > 0:
+    if world > 1 and args.allgather_cols > 0 and not args.compact:
         from plonky2_ecdsa_amd.dist import all_gather_columns
         k = min(args.allgather_cols, p2e.VERIFY_COLS)
         barrier()
@@ -238,6 +251,10 @@ def main():
                     "traffic_source": pmc.get("source")}
 
         runs_line, expand_line = roofline("k_expand_runs", kstat["runs"]), roofline("k_expand", kstat["expand"])
+        bytes_per_fill = BYTES_PER_FILL
+        if args.compact:   # the per-kernel byte counts above assume 8-byte columns: not quoted for this container
+            runs_line = expand_line = None
+            bytes_per_fill = 160 + NN * 4 + NW * 8
         line = {
             "metric": "secp256k1 ECDSA witness fills/sec at batch=2^16, 1/2/4/8 MI355X; bit-exact",
             "value": round(value, 1), "unit": "fills/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -246,12 +263,14 @@ def main():
             "config": {"workload": f"batch 2^{args.batch_log2} ECDSA verifies per GPU (BASELINE configs[3] workload on "
                                    "one GPU; random valid signatures, seed 4), all 82615 hot-path generator columns, "
                                    "column-major u64 in HBM",
+                       "container": "compact (u32 narrow + u64 wide matrices), NOT the headline format" if args.compact
+                                    else "u64 column matrix",
                        "batch_per_gpu": n, "global_batch": total, "cols_per_fill": p2e.VERIFY_COLS, "ld": ld,
                        "pipeline_depth": depth,
                        "parallelism": f"shard{world}" if world > 1 else "single"},
-            "whole_fill": {"algorithmic_bytes_per_fill": BYTES_PER_FILL,
-                           "GBps_per_gpu": round(value * BYTES_PER_FILL / world / 1e9, 1),
-                           "frac_of_hbm_peak": round(value * BYTES_PER_FILL / world / 1e9 / HBM_PEAK_GBS, 4)},
+            "whole_fill": {"algorithmic_bytes_per_fill": bytes_per_fill,
+                           "GBps_per_gpu": round(value * bytes_per_fill / world / 1e9, 1),
+                           "frac_of_hbm_peak": round(value * bytes_per_fill / world / 1e9 / HBM_PEAK_GBS, 4)},
             "phase_ms_per_step": {k: round(v / args.steps, 4) for k, v in phase_acc.items()},
             # P2E_RUN_ITERS=0 expands everything op by op: k_expand is then the only expansion kernel
             "roofline": runs_line or expand_line,

@@ -172,6 +172,16 @@ long p2e_columns_to_rows(p2e_ctx *ctx, const uint64_t *cols, size_t ld, size_t n
 long p2e_compact_layout(int program, uint32_t *col_map, size_t cap, uint32_t *num_narrow, uint32_t *num_wide);
 long p2e_columns_compact(p2e_ctx *ctx, int program, const uint64_t *cols, size_t ld, size_t n, uint32_t *narrow,
                          size_t ld_narrow, uint64_t *wide, size_t ld_wide, uint8_t *err);
+/* The fused schedules writing the compact container directly (same values, same err / valid semantics as
+ * p2e_ecdsa_verify_witness_batch / p2e_glv_mul_witness_batch; 28 % fewer bytes leave the kernels):
+ * narrow[num_narrow][ld_narrow] u32, wide[num_wide][ld_wide] u64, ld_narrow >= n, ld_wide >= n. */
+long p2e_ecdsa_verify_witness_compact_batch(p2e_ctx *ctx, const uint8_t *msg32, const uint8_t *r32, const uint8_t *s32,
+                                            const uint8_t *pkx32, const uint8_t *pky32, uint32_t *narrow,
+                                            size_t ld_narrow, uint64_t *wide, size_t ld_wide, size_t n, uint8_t *err,
+                                            uint8_t *valid);
+long p2e_glv_mul_witness_compact_batch(p2e_ctx *ctx, const uint8_t *px32, const uint8_t *py32, const uint8_t *k32,
+                                       uint32_t *narrow, size_t ld_narrow, uint64_t *wide, size_t ld_wide, size_t n,
+                                       uint8_t *err, uint8_t *valid);
 
 /* ---- schedule description (column -> generator map, host only, no GPU needed) ---------------------- */
 typedef struct p2e_gen_desc {

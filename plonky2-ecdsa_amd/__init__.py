@@ -48,7 +48,8 @@ EXPORTS = (
     "p2e_limb_pack", "p2e_ecdsa_verify_witness_batch", "p2e_glv_mul_witness_batch", "p2e_columns_to_rows",
     "p2e_schedule_describe",
     "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
-    "p2e_compact_layout", "p2e_columns_compact",
+    "p2e_compact_layout", "p2e_columns_compact", "p2e_ecdsa_verify_witness_compact_batch",
+    "p2e_glv_mul_witness_compact_batch",
 )
 
 
@@ -380,6 +381,41 @@ class Context:
                                                       _ptr(narrow), C.c_size_t(ld_narrow or self._shape(narrow)[1]), _ptr(wide),
                                                       C.c_size_t(ld_wide or self._shape(wide)[1]), _ptr(err)))
         return narrow, wide, err, bad
+
+    def _compact_out(self, program, n, narrow, wide, ld_narrow, ld_wide):
+        _m, nn, nw = compact_layout(program)
+        if narrow is None or wide is None:
+            ldp = n + 16 if (not self.host_pointers and n >= 4096 and n & (n - 1) == 0) else n   # see ecdsa_verify_witness_batch
+            if self.host_pointers:
+                narrow, wide = np.zeros((nn, ldp), dtype=np.uint32), np.zeros((nw, ldp), dtype=np.uint64)
+            else:
+                import torch
+                dev = f"cuda:{self.device}"
+                narrow = torch.empty((nn, ldp), dtype=torch.int32, device=dev)
+                wide = torch.empty((nw, ldp), dtype=torch.int64, device=dev)
+        return narrow, wide, ld_narrow or self._shape(narrow)[1], ld_wide or self._shape(wide)[1]
+
+    def ecdsa_verify_witness_compact_batch(self, msg, r, s, pkx, pky, narrow=None, wide=None, err=None, valid=None,
+                                           ld_narrow=None, ld_wide=None):
+        """ecdsa_verify_witness_batch writing the compact container (include/p2e.h): (narrow u32, wide u64, err, valid, bad)."""
+        n = self._shape(msg)[0]
+        narrow, wide, ldn, ldw = self._compact_out(PROGRAM_VERIFY, n, narrow, wide, ld_narrow, ld_wide)
+        err = err if err is not None else self._vec(n, np.uint8)
+        valid = valid if valid is not None else self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_ecdsa_verify_witness_compact_batch(
+            self._h, _ptr(msg), _ptr(r), _ptr(s), _ptr(pkx), _ptr(pky), _ptr(narrow), C.c_size_t(ldn), _ptr(wide), C.c_size_t(ldw),
+            C.c_size_t(n), _ptr(err), _ptr(valid)))
+        return narrow, wide, err, valid, bad
+
+    def glv_mul_witness_compact_batch(self, px, py, k, narrow=None, wide=None, err=None, valid=None, ld_narrow=None, ld_wide=None):
+        n = self._shape(px)[0]
+        narrow, wide, ldn, ldw = self._compact_out(PROGRAM_GLV_MUL, n, narrow, wide, ld_narrow, ld_wide)
+        err = err if err is not None else self._vec(n, np.uint8)
+        valid = valid if valid is not None else self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_glv_mul_witness_compact_batch(
+            self._h, _ptr(px), _ptr(py), _ptr(k), _ptr(narrow), C.c_size_t(ldn), _ptr(wide), C.c_size_t(ldw), C.c_size_t(n),
+            _ptr(err), _ptr(valid)))
+        return narrow, wide, err, valid, bad
 
     def glv_mul_witness_batch(self, px, py, k, cols=None, err=None, valid=None, ld=None):
         """glv_mul (gadgets/glv.rs:87-104): (65243, n) Goldilocks columns."""

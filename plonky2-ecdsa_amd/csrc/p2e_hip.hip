@@ -35,14 +35,17 @@ __device__ __forceinline__ size_t lane_sig(size_t first) {
     if (WIDE) return base + (t & ~63u) + 2u * (t & 31u) + ((t >> 5) & 1u);
     return base + t;
 }
-template <bool WIDE>
+// MODE of the emitting kernels: bit 0 = paired stores over full workgroups (else one signature per lane, ragged tail),
+// bit 1 = compact container (u32 narrow + u64 wide matrices) instead of the u64 column matrix
+template <int MODE> struct EmitOf;
+template <> struct EmitOf<0> { typedef Emit type; };
+template <> struct EmitOf<1> { typedef PairEmit type; };
+template <> struct EmitOf<2> { typedef CompactEmit type; };
+template <> struct EmitOf<3> { typedef CompactPairEmit type; };
+template <int MODE>
 __global__ __launch_bounds__(BS) void k_scalar(Program G, Buffers B, size_t first) {
-    size_t i = lane_sig<WIDE>(first);
-    if (WIDE) {
-        body_scalar<PairEmit>(G, B, i);
-    } else if (i < B.n) {
-        body_scalar<Emit>(G, B, i);
-    }
+    size_t i = lane_sig<(MODE & 1) != 0>(first);
+    if ((MODE & 1) || i < B.n) body_scalar<typename EmitOf<MODE>::type>(G, B, i);
 }
 // ops [lo, hi) of a chain, sequential per lane
 __global__ __launch_bounds__(BS) void k_chains(Program G, Buffers B, int lo, int hi, int table_affine, int continue_prefix) {
@@ -64,26 +67,18 @@ __global__ __launch_bounds__(BS) void k_batch_inv(Program G, Buffers B, int lo, 
     if (i < B.n) body_batch_inv(G, B, i, lo, hi, have_prefix != 0);
 }
 // op lo + blockIdx.y
-template <bool WIDE>
+template <int MODE>
 __global__ __launch_bounds__(BS) void k_expand(Program G, Buffers B, int lo, size_t first) {
-    size_t i = lane_sig<WIDE>(first);
-    if (WIDE) {
-        body_expand<PairEmit>(G, B, i, lo + (int)blockIdx.y);
-    } else if (i < B.n) {
-        body_expand<Emit>(G, B, i, lo + (int)blockIdx.y);
-    }
+    size_t i = lane_sig<(MODE & 1) != 0>(first);
+    if ((MODE & 1) || i < B.n) body_expand<typename EmitOf<MODE>::type>(G, B, i, lo + (int)blockIdx.y);
 }
 // runs of MSM-loop iterations: run blockIdx.y of the launch covers iterations [it_first + y*R, +R) capped at it_end
-template <bool WIDE>
+template <int MODE>
 __global__ __launch_bounds__(BS) void k_expand_runs(Program G, Buffers B, int it_first, int run_iters, int it_end, size_t first) {
-    size_t i = lane_sig<WIDE>(first);
+    size_t i = lane_sig<(MODE & 1) != 0>(first);
     int it0 = it_first + (int)blockIdx.y * run_iters;
     int it1 = it0 + run_iters < it_end ? it0 + run_iters : it_end;
-    if (WIDE) {
-        body_expand_run<PairEmit>(G, B, i, it0, it1);
-    } else if (i < B.n) {
-        body_expand_run<Emit>(G, B, i, it0, it1);
-    }
+    if ((MODE & 1) || i < B.n) body_expand_run<typename EmitOf<MODE>::type>(G, B, i, it0, it1);
 }
 // built-in-generator columns from the finished witness matrix: one (signature, item) per lane (aux.hpp)
 template <bool WIDE>
@@ -327,6 +322,8 @@ struct DeviceProgram {
     std::vector<u32> compact_map;
     u32 num_narrow = 0, num_wide = 0;
     u32* d_compact_map = nullptr;
+    std::vector<u32> wide_before;   // [num_cols + 1]: wide columns before column c (Sink::wide_before)
+    u32* d_wide_before = nullptr;
 };
 
 struct p2e_ctx {
@@ -374,6 +371,9 @@ static void build_compact_map(DeviceProgram& P) {
             const bool wide = g.kind == host::GEN_MUL && k >= 2 * NL;
             P.compact_map[g.col + k] = wide ? (COMPACT_WIDE | P.num_wide++) : P.num_narrow++;
         }
+    P.wide_before.assign((size_t)P.prog.num_cols + 1, 0);
+    for (size_t col = 0; col < P.compact_map.size(); col++)
+        P.wide_before[col + 1] = P.wide_before[col] + ((P.compact_map[col] & COMPACT_WIDE) ? 1u : 0u);
 }
 static const DeviceProgram& host_program(int program) {
     static DeviceProgram P[2];
@@ -494,6 +494,8 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         c->progs[p].num_wide = HP.num_wide;
         HIP_TRY(hipMalloc(&c->progs[p].d_compact_map, sizeof(u32) * HP.compact_map.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_compact_map, HP.compact_map.data(), sizeof(u32) * HP.compact_map.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&c->progs[p].d_wide_before, sizeof(u32) * HP.wide_before.size()));
+        HIP_TRY(hipMemcpy(c->progs[p].d_wide_before, HP.wide_before.data(), sizeof(u32) * HP.wide_before.size(), hipMemcpyHostToDevice));
         std::vector<OpDesc> plain = host_ops(p, 0);
         HIP_TRY(hipMalloc(&c->progs[p].d_ops_plain, sizeof(OpDesc) * plain.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_ops_plain, plain.data(), sizeof(OpDesc) * plain.size(), hipMemcpyHostToDevice));
@@ -535,6 +537,7 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
         (void)hipFree(p.d_aux_items);
         (void)hipFree(p.d_aux_tab);
         (void)hipFree(p.d_compact_map);
+        (void)hipFree(p.d_wide_before);
     }
     (void)hipFree(c->scratch);
     (void)hipFree(c->d_counter);
@@ -828,9 +831,11 @@ extern "C" long p2e_limb_pack(p2e_ctx* c, const uint64_t* limbs, uint8_t* packed
 // ====================================================================================================
 // fused schedules
 // ====================================================================================================
+// cols != nullptr: the u64 column matrix; otherwise the compact container (narrow, wide)
 static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8_t* r, const uint8_t* s,
                         const uint8_t* pkx, const uint8_t* pky, uint64_t* cols, size_t n, size_t ld, uint8_t* err,
-                        uint8_t* valid) {
+                        uint8_t* valid, uint32_t* narrow = nullptr, size_t ldn = 0, uint64_t* wide = nullptr, size_t ldw = 0) {
+    const bool compact = cols == nullptr;
     const DeviceProgram& DP = c->progs[program];
     const Program& G = DP.prog;
     Staged S(c);
@@ -839,7 +844,12 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     s = S.in(s, n * 32);
     pkx = S.in(pkx, n * 32);
     pky = S.in(pky, n * 32);
-    cols = S.out(cols, (size_t)G.num_cols * ld * 8);
+    if (compact) {
+        narrow = S.out(narrow, (size_t)DP.num_narrow * ldn * 4);
+        wide = S.out(wide, (size_t)DP.num_wide * ldw * 8);
+    } else {
+        cols = S.out(cols, (size_t)G.num_cols * ld * 8);
+    }
     err = S.out(err, n);
     valid = S.out(valid, n);
     if (S.rc) return S.done(S.rc);
@@ -853,8 +863,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     B.s = s;
     B.pkx = pkx;
     B.pky = pky;
-    B.out = cols;
-    B.ld = ld;
+    B.sink = Sink{cols, ld, narrow, ldn, wide, ldw, DP.d_wide_before};
     B.n = n;
     B.err = (u32*)(base + L.err32);
     B.valid = (uint8_t*)(base + L.valid8);
@@ -877,7 +886,22 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     unsigned gx = (unsigned)((n + BS - 1) / BS);
     c->n_expand = 0;
     // 16-byte column stores need full workgroups, an even column stride and a 16-byte aligned matrix
-    const bool wide_ok = (ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(cols) & 15) == 0) && !getenv("P2E_NARROW_STORES");
+    // paired stores need full workgroups, even column strides and matrices aligned to two elements
+    const bool wide_ok = !getenv("P2E_NARROW_STORES") &&
+                         (compact ? (ldn % 2 == 0 && ldw % 2 == 0 && (reinterpret_cast<uintptr_t>(narrow) & 7) == 0 &&
+                                     (reinterpret_cast<uintptr_t>(wide) & 15) == 0)
+                                  : (ld % 2 == 0 && (reinterpret_cast<uintptr_t>(cols) & 15) == 0));
+    // kernel variant per launch: EmitOf<MODE>
+#define LAUNCH_EMIT(KERNEL, PAIRED, GRID, STREAM, ...)                                                    \
+    do {                                                                                                  \
+        if (compact) {                                                                                    \
+            if (PAIRED) hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(BS), 0, STREAM, __VA_ARGS__);            \
+            else hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(BS), 0, STREAM, __VA_ARGS__);                   \
+        } else {                                                                                          \
+            if (PAIRED) hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(BS), 0, STREAM, __VA_ARGS__);            \
+            else hipLaunchKernelGGL(KERNEL<0>, GRID, dim3(BS), 0, STREAM, __VA_ARGS__);                   \
+        }                                                                                                 \
+    } while (0)
     const size_t n_wide = wide_ok ? (n / BS) * BS : 0;
     const unsigned gx_wide = (unsigned)(n_wide / BS);
     const unsigned gx_tail = (unsigned)((n - n_wide + BS - 1) / BS);
@@ -941,8 +965,8 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     if (verify) segs[ns - 1].final_after = true;
 
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    if (gx_wide) hipLaunchKernelGGL(k_scalar<true>, dim3(gx_wide), dim3(BS), 0, c->stream, G, B, (size_t)0);
-    if (gx_tail) hipLaunchKernelGGL(k_scalar<false>, dim3(gx_tail), dim3(BS), 0, c->stream, G, B, n_wide);
+    if (gx_wide) LAUNCH_EMIT(k_scalar, true, dim3(gx_wide), c->stream, G, B, (size_t)0);
+    if (gx_tail) LAUNCH_EMIT(k_scalar, false, dim3(gx_tail), c->stream, G, B, n_wide);
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->st_msm, c->ev_fork, 0));
@@ -1015,10 +1039,8 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             const unsigned nr = (unsigned)((sg.it1 - sg.it0 + R - 1) / R);
             const int e = c->n_expand++;
             HIP_TRY(hipEventRecord(c->ev_c0[e], c->stream));
-            if (gx_wide)
-                hipLaunchKernelGGL(k_expand_runs<true>, dim3(gx_wide, nr), dim3(BS), 0, c->stream, G, B, sg.it0, R, sg.it1, (size_t)0);
-            if (gx_tail)
-                hipLaunchKernelGGL(k_expand_runs<false>, dim3(gx_tail, nr), dim3(BS), 0, c->stream, G, B, sg.it0, R, sg.it1, n_wide);
+            if (gx_wide) LAUNCH_EMIT(k_expand_runs, true, dim3(gx_wide, nr), c->stream, G, B, sg.it0, R, sg.it1, (size_t)0);
+            if (gx_tail) LAUNCH_EMIT(k_expand_runs, false, dim3(gx_tail, nr), c->stream, G, B, sg.it0, R, sg.it1, n_wide);
             HIP_TRY(hipEventRecord(c->ev_c1[e], c->stream));
             c->expand_kind[e] = 1;
             c->expand_cols[e] = cols_of(G.msm_loop_begin + 3 * sg.it0, G.msm_loop_begin + 3 * sg.it1);
@@ -1026,10 +1048,8 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         if (sg.s_hi > sg.s_lo) {
             const int e = c->n_expand++;
             HIP_TRY(hipEventRecord(c->ev_c0[e], c->stream));
-            if (gx_wide)
-                hipLaunchKernelGGL(k_expand<true>, dim3(gx_wide, (unsigned)(sg.s_hi - sg.s_lo)), dim3(BS), 0, c->stream, G, B, sg.s_lo, (size_t)0);
-            if (gx_tail)
-                hipLaunchKernelGGL(k_expand<false>, dim3(gx_tail, (unsigned)(sg.s_hi - sg.s_lo)), dim3(BS), 0, c->stream, G, B, sg.s_lo, n_wide);
+            if (gx_wide) LAUNCH_EMIT(k_expand, true, dim3(gx_wide, (unsigned)(sg.s_hi - sg.s_lo)), c->stream, G, B, sg.s_lo, (size_t)0);
+            if (gx_tail) LAUNCH_EMIT(k_expand, false, dim3(gx_tail, (unsigned)(sg.s_hi - sg.s_lo)), c->stream, G, B, sg.s_lo, n_wide);
             HIP_TRY(hipEventRecord(c->ev_c1[e], c->stream));
             c->expand_kind[e] = 0;
             c->expand_cols[e] = cols_of(sg.s_lo, sg.s_hi);
@@ -1039,6 +1059,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, B.err, B.valid, err, valid, n, c->d_counter);
     c->have_phases = true;
     return S.done(finish_call(c));
+#undef LAUNCH_EMIT
 }
 
 extern "C" long p2e_ecdsa_verify_witness_batch(p2e_ctx* c, const uint8_t* msg32, const uint8_t* r32,
@@ -1053,6 +1074,22 @@ extern "C" long p2e_glv_mul_witness_batch(p2e_ctx* c, const uint8_t* px32, const
     if (bad_common(c, n, ld) || !px32 || !py32 || !k32 || !cols || !err) return P2E_E_INVALID;
     if (n == 0) return 0;
     return run_program(c, 1, k32, k32, k32, px32, py32, cols, n, ld, err, valid);
+}
+
+extern "C" long p2e_ecdsa_verify_witness_compact_batch(p2e_ctx* c, const uint8_t* msg32, const uint8_t* r32, const uint8_t* s32,
+                                                       const uint8_t* pkx32, const uint8_t* pky32, uint32_t* narrow, size_t ld_narrow,
+                                                       uint64_t* wide, size_t ld_wide, size_t n, uint8_t* err, uint8_t* valid) {
+    if (bad_common(c, n, ld_narrow) || ld_wide < n || !msg32 || !r32 || !s32 || !pkx32 || !pky32 || !narrow || !wide || !err)
+        return P2E_E_INVALID;
+    if (n == 0) return 0;
+    return run_program(c, 0, msg32, r32, s32, pkx32, pky32, nullptr, n, 0, err, valid, narrow, ld_narrow, wide, ld_wide);
+}
+extern "C" long p2e_glv_mul_witness_compact_batch(p2e_ctx* c, const uint8_t* px32, const uint8_t* py32, const uint8_t* k32,
+                                                  uint32_t* narrow, size_t ld_narrow, uint64_t* wide, size_t ld_wide, size_t n,
+                                                  uint8_t* err, uint8_t* valid) {
+    if (bad_common(c, n, ld_narrow) || ld_wide < n || !px32 || !py32 || !k32 || !narrow || !wide || !err) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    return run_program(c, 1, k32, k32, k32, px32, py32, nullptr, n, 0, err, valid, narrow, ld_narrow, wide, ld_wide);
 }
 
 extern "C" long p2e_columns_to_rows(p2e_ctx* c, const uint64_t* cols, size_t ld, size_t n, size_t ncols,

@@ -72,8 +72,8 @@ struct Program {
 struct Buffers {
     // inputs, packed 32-byte little-endian, element i at +32*i
     const uint8_t *msg, *r, *s, *pkx, *pky;  // glv_mul-only: pkx, pky, and k in `msg`
-    u64* out;
-    size_t ld, n;
+    Sink sink;       // where the witness values go (u64 column matrix, or the compact container)
+    size_t n;
     u32* err;        // per-element error bits (never null; OR-ed atomically by phases B and C)
     uint8_t* valid;  // per-element "all connect constraints hold" (never null)
     // scratch, [slot][n]: Jacobian points + numerator of v^-1 (phase A), prefix products and affine points (phase B)
@@ -122,7 +122,7 @@ P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
     if (G.full_verify) {
         U256 msg = load_packed(B.msg, i), r = load_packed(B.r, i), s = load_packed(B.s, i);
         {  // curve_assert_valid gadgets/curve.rs:123-135
-            E e = E::at(B.out, B.ld, i, (u32)G.sc.assert_valid);
+            E e = E::at(B.sink, i, (u32)G.sc.assert_valid);
             U256 y2 = wit_mul<ModP>(e, py, py, err);
             U256 x2 = wit_mul<ModP>(e, px, px, err);
             U256 x3 = wit_mul<ModP>(e, x2, px, err);
@@ -132,7 +132,7 @@ P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
             ok = ok && u256_eq(y2, rhs);
             e.flush();
         }
-        E e = E::at(B.out, B.ld, i, (u32)G.sc.inv_s);
+        E e = E::at(B.sink, i, (u32)G.sc.inv_s);
         U256 c = wit_inv<ModN>(e, s, err);        // gadgets/ecdsa.rs:40
         U256 u1 = wit_mul<ModN>(e, msg, c, err);  // :41
         k = wit_mul<ModN>(e, r, c, err);          // :42
@@ -144,7 +144,7 @@ P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
     // decompose_secp256k1_scalar gadgets/glv.rs:53-85
     GlvOut g = glv_decompose(k);
     {
-        E e = E::at(B.out, B.ld, i, (u32)G.sc.glv);
+        E e = E::at(B.sink, i, (u32)G.sc.glv);
         u32 l[NL];
         split29(g.k1, l);
         emit_limbs(e, l, 5);
@@ -185,13 +185,13 @@ P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
             beta.w[2 * q + 1] = (u32)(bv[q] >> 32);
         }
     }
-    E e1 = E::at(B.out, B.ld, i, (u32)G.sc.beta_x);
+    E e1 = E::at(B.sink, i, (u32)G.sc.beta_x);
     U256 bx = wit_mul<ModP>(e1, beta, px, err);
     e1.flush();
-    E e2 = E::at(B.out, B.ld, i, (u32)G.sc.neg_p);
+    E e2 = E::at(B.sink, i, (u32)G.sc.neg_p);
     U256 y1 = wit_cond_neg<ModP>(e2, py, g.n1);
     e2.flush();
-    E e3 = E::at(B.out, B.ld, i, (u32)G.sc.neg_sp);
+    E e3 = E::at(B.sink, i, (u32)G.sc.neg_sp);
     U256 y2 = wit_cond_neg<ModP>(e3, py, g.n2);
     e3.flush();
     size_t sp = (size_t)G.slot_p * B.n + i, ssp = (size_t)G.slot_sp * B.n + i;
@@ -443,7 +443,7 @@ template <class E>
 P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t) {
     const OpDesc op = B.ops[t];
     uint8_t err = 0;
-    E e = E::at(B.out, B.ld, i, op.col);
+    E e = E::at(B.sink, i, op.col);
     // operands were resolved by phase A: one level of index loads, then the points
     const uint16_t s1 = B.src[(size_t)(2 * t) * B.n + i];
     const uint16_t s2 = op.kind == OP_DBL ? (uint16_t)0 : B.src[(size_t)(2 * t + 1) * B.n + i];
@@ -484,7 +484,7 @@ P2E_HD void body_expand_run(const Program& G, const Buffers& B, size_t i, int it
 #pragma unroll 1
 #endif
         for (int k = 0; k < 2; k++) {  // curve_repeated_double(result, 2)
-            E e = E::at(B.out, B.ld, i, B.ops[t + k].col);
+            E e = E::at(B.sink, i, B.ops[t + k].col);
             p = wit_curve_double(e, p, B.PW[(size_t)(t + k) * B.n + i], err);
             e.flush();
         }
@@ -492,7 +492,7 @@ P2E_HD void body_expand_run(const Program& G, const Buffers& B, size_t i, int it
         const uint16_t s2 = B.src[(size_t)(2 * tc + 1) * B.n + i];
         Aff p2 = load_aff_src(B, i, (uint16_t)(s2 & (DYN_CONST_BIT | SRC_ID_MASK)));
         const bool b = (s2 & SRC_SEL_BIT) != 0;
-        E e = E::at(B.out, B.ld, i, B.ops[tc].col);
+        E e = E::at(B.sink, i, B.ops[tc].col);
         Aff sm = wit_curve_add(e, p, p2, B.PW[(size_t)tc * B.n + i], err);
         const U256 z = u256_zero();
         Aff nx;

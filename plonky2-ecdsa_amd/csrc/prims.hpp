@@ -14,6 +14,9 @@ struct ArrEmit {
     P2E_HD void put(u64 v) { a[k++] = v; }
     P2E_HD void put_at(int d, u64 v) { a[k + d] = v; }
     P2E_HD void skip(int d) { k += d; }
+    P2E_HD void put_wide(u64 v) { put(v); }
+    P2E_HD void put_wide_at(int d, u64 v) { put_at(d, v); }
+    P2E_HD void skip_wide(int d) { skip(d); }
 };
 
 // sum limb_k * 2^(29k) for arbitrary 64-bit limbs; false if the value is >= 2^256

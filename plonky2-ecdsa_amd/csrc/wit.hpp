@@ -17,7 +17,24 @@
 
 namespace p2e {
 
-// cursor over one signature's column of the output matrix: plain 8-byte stores (one per lane per column)
+// Where a fused kernel's witness values go: the u64 column matrix out[col * ld + sig], or the compact container of
+// include/p2e.h (p2e_columns_compact): u32 nar[narrow index][ldn] for the columns that only hold limbs, overflow
+// words and flags, u64 wid[wide index][ldw] for the check_sum / carry columns of the mul generators.  Both indices
+// advance in registration order, so a cursor opened at column `col` starts at wide index wide_before[col] and narrow
+// index col - wide_before[col].
+struct Sink {
+    u64* out;
+    size_t ld;
+    u32* nar;
+    size_t ldn;
+    u64* wid;
+    size_t ldw;
+    const u32* wide_before;   // [num_cols + 1]
+};
+
+// cursor over one signature's column of the output matrix: plain 8-byte stores (one per lane per column).
+// put_wide / put_wide_at / skip_wide mark the values that need all 64 bits (check_sum, carries): the same
+// stream here, a separate matrix in the compact emitters below.
 struct Emit {
     u64* p;      // &out[col * ld + sig]
     size_t ld;   // column stride in elements
@@ -27,6 +44,7 @@ struct Emit {
         e.ld = ld_;
         return e;
     }
+    P2E_HD static Emit at(const Sink& S, size_t sig, u32 col) { return at(S.out, S.ld, sig, col); }
     P2E_HD void put(u64 v) {
         *p = v;
         p += ld;
@@ -34,37 +52,67 @@ struct Emit {
     // store k columns ahead of the cursor without moving it
     P2E_HD void put_at(int k, u64 v) { p[(size_t)k * ld] = v; }
     P2E_HD void skip(int k) { p += (size_t)k * ld; }
+    P2E_HD void put_wide(u64 v) { put(v); }
+    P2E_HD void put_wide_at(int k, u64 v) { put_at(k, v); }
+    P2E_HD void skip_wide(int k) { skip(k); }
+    P2E_HD void flush() {}
+};
+// the same for the compact container: 4-byte stores into the narrow matrix, 8-byte stores into the wide one
+struct CompactEmit {
+    u32* pn;
+    u64* pw;
+    size_t ldn, ldw;
+    P2E_HD static CompactEmit at(const Sink& S, size_t sig, u32 col) {
+        CompactEmit e;
+        const u32 wb = S.wide_before[col];
+        e.pn = S.nar + (size_t)(col - wb) * S.ldn + sig;
+        e.pw = S.wid + (size_t)wb * S.ldw + sig;
+        e.ldn = S.ldn;
+        e.ldw = S.ldw;
+        return e;
+    }
+    P2E_HD void put(u64 v) {
+        *pn = (u32)v;
+        pn += ldn;
+    }
+    P2E_HD void put_wide(u64 v) {
+        *pw = v;
+        pw += ldw;
+    }
+    P2E_HD void put_wide_at(int k, u64 v) { pw[(size_t)k * ldw] = v; }
+    P2E_HD void skip_wide(int k) { pw += (size_t)k * ldw; }
     P2E_HD void flush() {}
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// Same interface, 16-byte stores.  The column stores of the fused kernels are store-ISSUE bound with
-// 8 B per lane (MI355X_MICROARCH.md "store tail": ~7 B/clk/CU), so two consecutive columns c, c+1 are
-// written with ONE global_store_dwordx4 per lane: the wave's lanes l and l+32 own ADJACENT signatures
-// (sig = base + 2*(l & 31) + (l >> 5)), a v_permlane32_swap pair exchanges "my column-c+1 value" of the
-// lower half with "my column-c value" of the upper half, after which lower lanes hold column c of
-// signatures (2l, 2l+1) and upper lanes column c+1 of the same two signatures: 16 contiguous bytes each,
-// 512 contiguous bytes per half-wave.  Requires EXEC = all ones (full waves), ld even, 16-byte aligned
-// base; the launcher falls back to Emit otherwise.  All bookkeeping below (column counters, "have a
-// pending value") is compile-time after inlining: every put sequence is static.
-struct PairEmit {
+// Paired column stores.  The column stores of the fused kernels are store-ISSUE bound with 8 B per lane
+// (MI355X_MICROARCH.md "store tail": ~7 B/clk/CU), so two consecutive columns c, c+1 are written with ONE
+// store per lane: the wave's lanes l and l+32 own ADJACENT signatures (sig = base + 2*(l & 31) + (l >> 5)), a
+// v_permlane32_swap exchanges "my column-c+1 value" of the lower half with "my column-c value" of the upper
+// half, after which lower lanes hold column c of signatures (2l, 2l+1) and upper lanes column c+1 of the same
+// two signatures: 2 contiguous elements each (global_store_dwordx4 for u64 columns, dwordx2 for the u32 columns
+// of the compact container).  Requires EXEC = all ones (full waves), an even stride, a base aligned to two
+// elements; the launcher falls back to the plain emitters otherwise.  All bookkeeping below (column counters,
+// "have a pending value") is compile-time after inlining: every put sequence is static.
+template <class T>
+struct PStream {
     // All lane dependence lives in ONE running pointer that is bumped by the (wave-uniform) stride per column.
     // Computing `out + (c + upper) * ld + sig` per store instead costs two quarter-rate v_mad_u64_u32 each and,
     // inside the run-walking loop, makes the optimiser keep one hoisted VGPR per column constant of the body
     // (349 registers, one wave per SIMD).
-    u64* two;         // this lane's 16-byte slot of the column pair (col - 1, col): lags the cursor by one column
-    ptrdiff_t delta;  // this lane's 8-byte slot of column c is (its 16-byte slot of pair (c, c+1)) + delta
+    T* two;           // this lane's 2-element slot of the column pair (col - 1, col): lags the cursor by one column
+    ptrdiff_t delta;  // this lane's 1-element slot of column c is (its 2-element slot of pair (c, c+1)) + delta
     size_t ld;
-    int col;          // cursor, relative to col0
+    int col;          // cursor, relative to the opening column
     bool have, have2;
-    u64 pend, pend2;
+    T pend, pend2;
     int pcol, pcol2;
-    P2E_HD static PairEmit at(u64* out, size_t ld_, size_t sig_, u32 col0) {
-        PairEmit e;
+    P2E_HD static PStream at(T* col0 /* &m[opening column * ld] */, size_t ld_, size_t sig_) {
+        PStream e;
         const size_t upper = sig_ & 1;   // the lane mapping makes the signature's parity the half-wave index
         // lower half-wave: column c of signatures (sig, sig+1); upper: column c+1 of (sig-1, sig)
-        uintptr_t first = (uintptr_t)(out + (size_t)col0 * ld_ + (upper ? ld_ : 0) + (sig_ - upper));
-        e.two = (u64*)(first - 8 * ld_);
+        uintptr_t first = (uintptr_t)(col0 + (upper ? ld_ : 0) + (sig_ - upper));
+        e.two = (T*)(first - sizeof(T) * ld_);
         e.delta = upper ? (ptrdiff_t)1 - (ptrdiff_t)ld_ : 0;
         e.ld = ld_;
         e.col = 0;
@@ -73,27 +121,34 @@ struct PairEmit {
         e.pcol = e.pcol2 = 0;
         return e;
     }
-    P2E_HD u64* slot2(int c) const {   // c - (col - 1) is a compile-time constant at every call site
+    P2E_HD T* slot2(int c) const {   // c - (col - 1) is a compile-time constant at every call site
         const int d = c - (col - 1);
-        return d == 0 ? two : (u64*)((uintptr_t)two + (intptr_t)d * (intptr_t)(8 * ld));
+        return d == 0 ? two : (T*)((uintptr_t)two + (intptr_t)d * (intptr_t)(sizeof(T) * ld));
     }
     P2E_HD void bump(int k) {
-        two = (u64*)((uintptr_t)two + (size_t)k * 8 * ld);
+        two = (T*)((uintptr_t)two + (size_t)k * sizeof(T) * ld);
         asm("" : "+v"(two));   // keep it a running pointer: do not re-derive first + c * ld
         col += k;
     }
     // Output columns are write-once / never re-read by the pipeline: non-temporal stores keep them from
     // displacing the scratch arrays that phases B and C are about to read (-1.6 % on the whole step).
-    P2E_HD void store_single(int c, u64 v) { __builtin_nontemporal_store(v, slot2(c) + delta); }
-    P2E_HD void store_pair(int c, u64 a, u64 b) {   // a: my value of column c, b: of column c + 1
-        u32 ax = (u32)a, ay = (u32)(a >> 32), bx = (u32)b, by = (u32)(b >> 32);
-        auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-        auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-        v4u ov = {r0[0], r1[0], r0[1], r1[1]};
-        __builtin_nontemporal_store(ov, reinterpret_cast<v4u*>(slot2(c)));
+    P2E_HD void store_single(int c, T v) { __builtin_nontemporal_store(v, slot2(c) + delta); }
+    P2E_HD void store_pair(int c, T a, T b) {   // a: my value of column c, b: of column c + 1
+        if (sizeof(T) == 8) {
+            u32 ax = (u32)a, ay = (u32)((u64)a >> 32), bx = (u32)b, by = (u32)((u64)b >> 32);
+            auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+            v4u ov = {r0[0], r1[0], r0[1], r1[1]};
+            __builtin_nontemporal_store(ov, reinterpret_cast<v4u*>(slot2(c)));
+        } else {
+            auto r0 = __builtin_amdgcn_permlane32_swap((u32)a, (u32)b, false, false);
+            typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+            v2u ov = {r0[0], r0[1]};
+            __builtin_nontemporal_store(ov, reinterpret_cast<v2u*>(slot2(c)));
+        }
     }
-    P2E_HD void put(u64 v) {
+    P2E_HD void put(T v) {
         if (have && pcol + 1 == col) {
             store_pair(pcol, pend, v);
             have = false;
@@ -105,7 +160,7 @@ struct PairEmit {
         }
         bump(1);
     }
-    P2E_HD void put_at(int k, u64 v) {
+    P2E_HD void put_at(int k, T v) {
         const int c = col + k;
         if (have2 && pcol2 + 1 == c) {
             store_pair(pcol2, pend2, v);
@@ -124,8 +179,46 @@ struct PairEmit {
         have = have2 = false;
     }
 };
+// u64 column matrix, 16-byte stores
+struct PairEmit {
+    PStream<u64> s;
+    P2E_HD static PairEmit at(u64* out, size_t ld_, size_t sig_, u32 col0) {
+        PairEmit e;
+        e.s = PStream<u64>::at(out + (size_t)col0 * ld_, ld_, sig_);
+        return e;
+    }
+    P2E_HD static PairEmit at(const Sink& S, size_t sig, u32 col) { return at(S.out, S.ld, sig, col); }
+    P2E_HD void put(u64 v) { s.put(v); }
+    P2E_HD void put_at(int k, u64 v) { s.put_at(k, v); }
+    P2E_HD void skip(int k) { s.skip(k); }
+    P2E_HD void put_wide(u64 v) { s.put(v); }
+    P2E_HD void put_wide_at(int k, u64 v) { s.put_at(k, v); }
+    P2E_HD void skip_wide(int k) { s.skip(k); }
+    P2E_HD void flush() { s.flush(); }
+};
+// compact container: 8-byte stores of two u32 into the narrow matrix, 16-byte stores into the wide one
+struct CompactPairEmit {
+    PStream<u32> n;
+    PStream<u64> w;
+    P2E_HD static CompactPairEmit at(const Sink& S, size_t sig, u32 col) {
+        CompactPairEmit e;
+        const u32 wb = S.wide_before[col];
+        e.n = PStream<u32>::at(S.nar + (size_t)(col - wb) * S.ldn, S.ldn, sig);
+        e.w = PStream<u64>::at(S.wid + (size_t)wb * S.ldw, S.ldw, sig);
+        return e;
+    }
+    P2E_HD void put(u64 v) { n.put((u32)v); }
+    P2E_HD void put_wide(u64 v) { w.put(v); }
+    P2E_HD void put_wide_at(int k, u64 v) { w.put_at(k, v); }
+    P2E_HD void skip_wide(int k) { w.skip(k); }
+    P2E_HD void flush() {
+        n.flush();
+        w.flush();
+    }
+};
 #else
-typedef Emit PairEmit;   // host passes only parse the kernels that name it
+typedef Emit PairEmit;   // host passes only parse the kernels that name them
+typedef CompactEmit CompactPairEmit;
 #endif
 
 template <class E>
@@ -284,17 +377,17 @@ P2E_HD void emit_mul_rows(E& e, const u32* x29, const u32* y29, const u32* q29, 
             if (k >= 0 && k < NL) xy += (u64)x29[j] * y29[k];
         }
         i64 cs = (i64)(qm_column<MOD>(q29, i) - xy) + (i < NL ? (i64)r29[i] : 0);
-        e.put(gl_from_i64(cs));
+        e.put_wide(gl_from_i64(cs));
         if (i < 2 * NL - 2) {
             i64 t = cs + last;
             i64 bi = t >> BITS;  // exact: the integer is a multiple of 2^29 whenever q, r are right
             u64 bo = (u64)(bi + ((i64)1 << 33));
             if (bo >> 34) err |= ERR_CARRY_RANGE;
-            e.put_at(2 * NL - 2, bo);   // cursor already advanced past check_sum[i]: b[i] is 16 columns ahead
+            e.put_wide_at(2 * NL - 2, bo);   // cursor already advanced past check_sum[i]: b[i] is 16 columns ahead
             last = bi;
         }
     }
-    e.skip(2 * NL - 2);
+    e.skip_wide(2 * NL - 2);
 }
 
 // x, y: the values carried by the two operands' limbs (used RAW: reference quirk Q3), < 2^256

@@ -49,7 +49,8 @@ class EmuBackend:
     def __init__(self):
         self.L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libp2e_emu.so"))
         for f in ("emu_verify", "emu_glv_mul", "emu_mul", "emu_checksum", "emu_add", "emu_sub", "emu_add_many",
-                  "emu_inv", "emu_glv", "emu_split", "emu_pack", "emu_aux", "emu_aux_num_cols"):
+                  "emu_inv", "emu_glv", "emu_split", "emu_pack", "emu_aux", "emu_aux_num_cols", "emu_verify_compact",
+                  "emu_glv_mul_compact"):
             getattr(self.L, f).restype = C.c_long
 
     def mul(self, field, x, y):
@@ -144,6 +145,21 @@ def _emu_aux(self, program, inputs):
 
 
 EmuBackend.aux = _emu_aux
+
+
+def _emu_compact(self, program, inputs, nn, nw, run_iters=4):
+    """the fused walk writing the compact container directly (CompactEmit): (narrow u32, wide u64, err, valid)"""
+    arrs = [np.ascontiguousarray(a, np.uint8) for a in inputs]
+    n = arrs[0].shape[0]
+    narrow, wide = np.zeros((nn, n), np.uint32), np.zeros((nw, n), np.uint64)
+    err, valid = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    f = self.L.emu_verify_compact if program == 0 else self.L.emu_glv_mul_compact
+    f(*[_p(a) for a in arrs], _p(narrow), C.c_size_t(n), _p(wide), C.c_size_t(n), C.c_size_t(n), _p(err), _p(valid),
+      C.c_int(run_iters))
+    return narrow, wide, err, valid
+
+
+EmuBackend.compact = _emu_compact
 
 
 class GpuBackend:

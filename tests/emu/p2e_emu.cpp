@@ -13,9 +13,11 @@
 
 using namespace p2e;
 
+// E = Emit (u64 column matrix `cols`) or CompactEmit (narrow / wide matrices of the compact container)
+template <class E>
 static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx,
                 const uint8_t* pky, uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid, int chunk,
-                int run_iters) {
+                int run_iters, uint32_t* narrow = nullptr, size_t ldn = 0, uint64_t* wide = nullptr, size_t ldw = 0) {
     host::ScheduleBuilder sb;
     if (program == 0)
         sb.verify_secp256k1_message_circuit();
@@ -31,14 +33,20 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     std::vector<u32> err32(n);
     Buffers B{};
     B.msg = msg; B.r = r; B.s = s; B.pkx = pkx; B.pky = pky;
-    B.out = cols; B.ld = ld; B.n = n;
+    // wide_before[c] = check_sum / carry columns (33 per mul generator, after its r and q limbs) before column c
+    std::vector<u32> wide_before((size_t)G.num_cols + 1, 0);
+    for (const auto& g : sb.gens)
+        for (u32 k = 0; k < g.ncols; k++) wide_before[g.col + k + 1] = (g.kind == host::GEN_MUL && k >= 2 * NL) ? 1u : 0u;
+    for (size_t c2 = 1; c2 < wide_before.size(); c2++) wide_before[c2] += wide_before[c2 - 1];
+    B.sink = Sink{cols, ld, narrow, ldn, wide, ldw, wide_before.data()};
+    B.n = n;
     B.err = err32.data(); B.valid = valid8.data();
     B.PX = PX.data(); B.PY = PY.data(); B.PZ = PZ.data(); B.PW = PW.data(); B.PREF = PREF.data();
     B.AX = AX.data(); B.AY = AY.data();
     B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data(); B.src = src.data();
     B.cpts = C.cpts; B.fbtab = C.fbtab.data(); B.ops = sb.ops.data();
 #pragma omp parallel for
-    for (long long i = 0; i < (long long)n; i++) body_scalar<Emit>(G, B, (size_t)i);
+    for (long long i = 0; i < (long long)n; i++) body_scalar<E>(G, B, (size_t)i);
     // same dependency order as the stream plan of p2e_hip.hip, with the MSM chain cut into `pieces` pieces whose
     // phases B and C are interleaved with the following pieces of the chain
     // chunk >= piece length: one batch per piece using phase A's prefix products (what the GPU launches);
@@ -62,13 +70,13 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     auto expand = [&](int lo, int hi) {
 #pragma omp parallel for
         for (long long i = 0; i < (long long)n; i++)
-            for (int t = lo; t < hi; t++) body_expand<Emit>(G, B, (size_t)i, t);
+            for (int t = lo; t < hi; t++) body_expand<E>(G, B, (size_t)i, t);
     };
     auto expand_runs = [&](int it0, int it1) {
         for (int a = it0; a < it1; a += run_iters) {
             int b = a + run_iters < it1 ? a + run_iters : it1;
 #pragma omp parallel for
-            for (long long i = 0; i < (long long)n; i++) body_expand_run<Emit>(G, B, (size_t)i, a, b);
+            for (long long i = 0; i < (long long)n; i++) body_expand_run<E>(G, B, (size_t)i, a, b);
         }
     };
     // the same plan as run_program() in csrc/p2e_hip.hip: fixed-base chain; window table piece (inverted
@@ -177,11 +185,21 @@ long emu_bingcd_selfcheck(int field, unsigned long long seed, size_t n) {
 }
 long emu_verify(const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx, const uint8_t* pky,
                 uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid, int chunk, int run_iters) {
-    return run(0, msg, r, s, pkx, pky, cols, n, ld, err, valid, chunk, run_iters);
+    return run<Emit>(0, msg, r, s, pkx, pky, cols, n, ld, err, valid, chunk, run_iters);
+}
+// the same walk writing the compact container directly (CompactEmit: what the compact kernels' ragged tail runs)
+long emu_verify_compact(const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx, const uint8_t* pky,
+                        uint32_t* narrow, size_t ldn, uint64_t* wide, size_t ldw, size_t n, uint8_t* err, uint8_t* valid,
+                        int run_iters) {
+    return run<CompactEmit>(0, msg, r, s, pkx, pky, nullptr, n, 0, err, valid, 512, run_iters, narrow, ldn, wide, ldw);
+}
+long emu_glv_mul_compact(const uint8_t* px, const uint8_t* py, const uint8_t* k, uint32_t* narrow, size_t ldn, uint64_t* wide,
+                         size_t ldw, size_t n, uint8_t* err, uint8_t* valid, int run_iters) {
+    return run<CompactEmit>(1, k, k, k, px, py, nullptr, n, 0, err, valid, 512, run_iters, narrow, ldn, wide, ldw);
 }
 long emu_glv_mul(const uint8_t* px, const uint8_t* py, const uint8_t* k, uint64_t* cols, size_t n, size_t ld,
                  uint8_t* err, uint8_t* valid, int chunk, int run_iters) {
-    return run(1, k, k, k, px, py, cols, n, ld, err, valid, chunk, run_iters);
+    return run<Emit>(1, k, k, k, px, py, cols, n, ld, err, valid, chunk, run_iters);
 }
 // built-in-generator columns from a finished witness matrix (aux.hpp: the body k_aux runs)
 long emu_aux(int program, const uint8_t* pky, const uint64_t* cols, size_t ld, uint64_t* aux, size_t ald, size_t n,

@@ -267,6 +267,42 @@ def test_columns_compact_round_trip(n, pad):
     assert cbad == len(flagged) and 5 in flagged and set(flagged) <= {4, 5}
 
 
+@pytest.mark.parametrize("runs", [False, True], ids=["op_by_op", "run_expansion"])
+def test_fused_compact_output_matches_oracle(ora, monkeypatch, runs):
+    """The fused schedules writing the compact container directly (u32 narrow + u64 wide matrices): expanded on the
+    host it is the oracle's matrix.  n = 700: two full workgroups (paired 8- / 16-byte stores) + a ragged tail; padded
+    strides; both expansion kernels; both programs."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    if runs:
+        monkeypatch.setenv("P2E_RUNS_MIN_N", "0")
+    n = 700
+    sigs = p2e.synth_signatures(seed=71, n=n)
+    ctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    _m, nn, nw = p2e.compact_layout(0)
+    nar = torch.full((nn, n + 2), -1, dtype=torch.int32, device="cuda")
+    wid = torch.full((nw, n + 4), -1, dtype=torch.int64, device="cuda")
+    _, _, err, valid, bad = ctx.ecdsa_verify_witness_compact_batch(*dev, narrow=nar, wide=wid, ld_narrow=n + 2, ld_wide=n + 4)
+    torch.cuda.synchronize()
+    assert bad == 0 and int(valid.sum()) == n
+    want, _, _ = ora.verify(*sigs)
+    got = p2e.compact_expand(0, nar[:, :n].cpu().numpy().view(np.uint32), wid[:, :n].cpu().numpy())
+    assert np.array_equal(got, want)
+    assert bool((nar[:, n:] == -1).all()) and bool((wid[:, n:] == -1).all())
+    # and it is the same container p2e_columns_compact makes from the standard matrix
+    cols, _, _, _ = ctx.ecdsa_verify_witness_batch(*dev)
+    nar2, wid2, _, _ = ctx.columns_compact(0, cols, n=n, ld=cols.stride(0))
+    assert torch.equal(nar2, nar[:, :n]) and torch.equal(wid2, wid[:, :n])
+    # glv_mul program, host pointers (odd stride n = 700 is even; use the staged path)
+    hctx = p2e.Context(device=0, host_pointers=True)
+    rng = R.SplitMix64(72)
+    k = oracle_c.pack256([rng.below(R.N) for _ in range(n)])
+    gn, gw, gerr, _gvalid, gbad = hctx.glv_mul_witness_compact_batch(sigs[3], sigs[4], k)
+    assert gbad == 0
+    assert np.array_equal(p2e.compact_expand(1, gn, gw), ora.glv_mul(sigs[3], sigs[4], k)[0])
+
+
 def test_api_misuse_returns_status_not_crash():
     import plonky2_ecdsa_amd as p2e
     ctx = p2e.Context(device=0, host_pointers=True)

@@ -104,6 +104,23 @@ def test_compact_layout_is_a_partition_of_the_columns():
     assert int((cols[(m & p2e.COMPACT_WIDE) == 0] >> np.uint64(32)).max()) == 0
 
 
+@pytest.mark.parametrize("program", [0, 1])
+def test_compact_emitter_bodies_match_the_oracle(program):
+    """The fused walk with the compact emitter (u32 narrow / u64 wide cursors) expands back to the oracle's matrix."""
+    emu, ora = EmuBackend(), OracleBackend()
+    sigs = p2e.synth_signatures(seed=909, n=37)
+    if program == 0:
+        inputs, want = sigs, ora.verify(*sigs)[0]
+    else:
+        rng = R.SplitMix64(910)
+        inputs = [sigs[3], sigs[4], oracle_c.pack256([rng.below(R.N) for _ in range(37)])]
+        want = ora.glv_mul(*inputs)[0]
+    _m, nn, nw = p2e.compact_layout(program)
+    narrow, wide, err, _valid = emu.compact(program, inputs, nn, nw)
+    assert not err.any()
+    assert np.array_equal(p2e.compact_expand(program, narrow, wide), want)
+
+
 def test_synth_signatures_restates_sign_message():
     arrs = p2e.synth_signatures(seed=9, n=4, first=2)
     for i in range(4):
