@@ -15,8 +15,8 @@ ap.add_argument("--total-log2", type=int, default=17)
 ap.add_argument("--chunk-log2", type=int, default=13)
 ap.add_argument("--rows", action="store_true", help="transpose each chunk on the GPU so the host receives one contiguous "
                 "82615-element row per signature (what a per-signature PartialWitness fill reads)")
-ap.add_argument("--compact", action="store_true", help="repack each chunk on the GPU into the compact container (u32 narrow + u64 wide "
-                "matrices, p2e_columns_compact): 474 KB instead of 661 KB per signature over the host link")
+ap.add_argument("--compact", action="store_true", help="compute each chunk straight into the compact container (u32 narrow + u64 wide "
+                "matrices, p2e_ecdsa_verify_witness_compact_batch): 474 KB instead of 661 KB per signature over the host link")
 ap.add_argument("--check", type=int, default=4, help="signatures of the LAST chunk to verify against the oracle on the host copy")
 args = ap.parse_args()
 total, chunk = 1 << args.total_log2, 1 << args.chunk_log2
@@ -25,7 +25,7 @@ ld = chunk + 16
 ctx = p2e.Context(device=0)
 compute = torch.cuda.current_stream()
 copy = torch.cuda.Stream()
-dev_cols = [torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device="cuda") for _ in range(2)]
+dev_cols = [] if args.compact else [torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device="cuda") for _ in range(2)]
 if args.rows:
     dev_rows = [torch.empty((chunk, p2e.VERIFY_COLS), dtype=torch.int64, device="cuda") for _ in range(2)]
     host_cols = [torch.empty((chunk, p2e.VERIFY_COLS), dtype=torch.int64, pin_memory=True) for _ in range(2)]
@@ -35,7 +35,6 @@ elif args.compact:
     dev_wid = [torch.empty((NW, ld), dtype=torch.int64, device="cuda") for _ in range(2)]
     host_nar = [torch.empty((NN, ld), dtype=torch.int32, pin_memory=True) for _ in range(2)]
     host_wid = [torch.empty((NW, ld), dtype=torch.int64, pin_memory=True) for _ in range(2)]
-    cerr = torch.empty(chunk, dtype=torch.uint8, device="cuda")
 else:
     host_cols = [torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, pin_memory=True) for _ in range(2)]
 err = torch.empty(chunk, dtype=torch.uint8, device="cuda")
@@ -52,12 +51,14 @@ for k in range(nchunks):
     b = k & 1
     compute.wait_event(done_copy[b])            # buffer b free again (its previous copy finished)
     sl = [d[k * chunk:(k + 1) * chunk] for d in dev_in]
-    _, _, _, bad = ctx.ecdsa_verify_witness_batch(*sl, cols=dev_cols[b][:, :chunk], err=err, valid=valid, ld=ld)
+    if args.compact:   # the fused schedule writes the compact container directly
+        bad = ctx.ecdsa_verify_witness_compact_batch(*sl, narrow=dev_nar[b], wide=dev_wid[b], err=err, valid=valid,
+                                                     ld_narrow=ld, ld_wide=ld)[4]
+    else:
+        _, _, _, bad = ctx.ecdsa_verify_witness_batch(*sl, cols=dev_cols[b][:, :chunk], err=err, valid=valid, ld=ld)
     bad_total += bad
     if args.rows:
         ctx.columns_to_rows(dev_cols[b], n=chunk, ld=ld, rows=dev_rows[b])
-    if args.compact:
-        bad_total += ctx.columns_compact(0, dev_cols[b], n=chunk, ld=ld, narrow=dev_nar[b], wide=dev_wid[b], err=cerr)[3]
     done_compute[b].record(compute)
     with torch.cuda.stream(copy):
         copy.wait_event(done_compute[b])
