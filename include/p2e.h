@@ -145,6 +145,10 @@ long p2e_glv_mul_witness_batch(p2e_ctx *ctx, const uint8_t *px32, const uint8_t 
 #define P2E_GLV_MUL_AUX_COLS 4738
 long p2e_aux_witness_batch(p2e_ctx *ctx, int program, const uint8_t *pky32, const uint64_t *cols, size_t ld,
                            uint64_t *aux, size_t ld_aux, size_t n, uint8_t *err);
+/* The same pass inside the compact container: reads only its narrow matrix (every column this pass needs is a limb
+ * or a flag), writes aux as u32 aux32[P2E_*_AUX_COLS][ld_aux] (every value is a limb, a bit, a digit or a flag). */
+long p2e_aux_witness_compact_batch(p2e_ctx *ctx, int program, const uint8_t *pky32, const uint32_t *narrow,
+                                   size_t ld_narrow, uint32_t *aux32, size_t ld_aux, size_t n, uint8_t *err);
 typedef struct p2e_aux_desc {
     int32_t kind; /* 0 split4, 1 split2, 2 fixed-base window, 3 MSM digit, 4 conditional neg */
     uint32_t first_col, num_cols;

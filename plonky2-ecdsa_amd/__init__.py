@@ -49,7 +49,7 @@ EXPORTS = (
     "p2e_schedule_describe",
     "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
     "p2e_compact_layout", "p2e_columns_compact", "p2e_ecdsa_verify_witness_compact_batch",
-    "p2e_glv_mul_witness_compact_batch",
+    "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch",
 )
 
 
@@ -416,6 +416,24 @@ class Context:
             self._h, _ptr(px), _ptr(py), _ptr(k), _ptr(narrow), C.c_size_t(ldn), _ptr(wide), C.c_size_t(ldw), C.c_size_t(n),
             _ptr(err), _ptr(valid)))
         return narrow, wide, err, valid, bad
+
+    def aux_witness_compact_batch(self, program, pky, narrow, n=None, ld_narrow=None, aux32=None, err=None, ld_aux=None):
+        """aux_witness_batch inside the compact container: reads the narrow u32 matrix, writes a u32 aux matrix."""
+        n = n if n is not None else self._shape(pky)[0]
+        ld_narrow = ld_narrow if ld_narrow is not None else self._shape(narrow)[1]
+        if aux32 is None:
+            k = VERIFY_AUX_COLS if program == PROGRAM_VERIFY else GLV_MUL_AUX_COLS
+            if self.host_pointers:
+                aux32 = np.zeros((k, n), dtype=np.uint32)
+            else:
+                import torch
+                aux32 = torch.empty((k, n), dtype=torch.int32, device=f"cuda:{self.device}")
+        ld_aux = ld_aux if ld_aux is not None else self._shape(aux32)[1]
+        err = err if err is not None else self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_aux_witness_compact_batch(self._h, C.c_int(program), _ptr(pky), _ptr(narrow),
+                                                                C.c_size_t(ld_narrow), _ptr(aux32), C.c_size_t(ld_aux),
+                                                                C.c_size_t(n), _ptr(err)))
+        return aux32, err, bad
 
     def glv_mul_witness_batch(self, px, py, k, cols=None, err=None, valid=None, ld=None):
         """glv_mul (gadgets/glv.rs:87-104): (65243, n) Goldilocks columns."""

@@ -42,9 +42,9 @@ struct AuxTables {
     u32 num_aux_cols;
 };
 struct AuxArgs {
-    const u64* cols;  // finished witness matrix
-    size_t ld;
-    u64* aux;
+    const u64* cols;  // finished witness matrix, or null: read the compact container's narrow matrix instead (every
+    size_t ld;        // column this pass reads is a limb or a flag)
+    void* aux;        // u64 or u32 column matrix, by the emitter type
     size_t ald, n;
     const uint8_t* py;  // pk.y, packed
     const Aff* cpts;
@@ -52,9 +52,15 @@ struct AuxArgs {
     const AuxItem* items;
     const AuxTables* tab;
     u32* err;
+    const u32* nar;          // compact source: narrow matrix, its stride, wide columns before column c
+    size_t ldn;
+    const u32* wide_before;
 };
 
-P2E_HD u64 aux_col(const AuxArgs& A, u32 c, size_t i) { return A.cols[(size_t)c * A.ld + i]; }
+P2E_HD u64 aux_col(const AuxArgs& A, u32 c, size_t i) {
+    if (A.cols) return A.cols[(size_t)c * A.ld + i];
+    return A.nar[(size_t)(c - A.wide_before[c]) * A.ldn + i];
+}
 P2E_HD void aux_limbs_of(const U256& v, u64* l) {
     u32 s[NL];
     split29(v, s);
@@ -153,7 +159,7 @@ P2E_HD void aux_put_split(E& e, const AuxArgs& A, const AuxItem& it, size_t i) {
 template <class E>
 P2E_HD void body_aux(const AuxArgs& A, int item, size_t i) {
     const AuxItem it = A.items[item];
-    E e = E::at(A.aux, A.ald, i, it.aux_col);
+    E e = E::at(static_cast<typename E::elem*>(A.aux), A.ald, i, it.aux_col);
     if (it.kind == AUX_SPLIT4) {         // the scalar of fixed_base_curve_mul_circuit: 9 limbs
         aux_put_split<E, NL, 4>(e, A, it, i);
     } else if (it.kind == AUX_SPLIT2) {  // k1, k2 of the GLV decomposition: 5 limbs

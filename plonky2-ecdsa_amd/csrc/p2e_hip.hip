@@ -81,14 +81,16 @@ __global__ __launch_bounds__(BS) void k_expand_runs(Program G, Buffers B, int it
     if ((MODE & 1) || i < B.n) body_expand_run<typename EmitOf<MODE>::type>(G, B, i, it0, it1);
 }
 // built-in-generator columns from the finished witness matrix: one (signature, item) per lane (aux.hpp)
-template <bool WIDE>
+// MODE bit 0 = paired stores over full workgroups, bit 1 = u32 output matrix
+template <int MODE> struct AuxEmitOf;
+template <> struct AuxEmitOf<0> { typedef Emit type; };
+template <> struct AuxEmitOf<1> { typedef PairEmit type; };
+template <> struct AuxEmitOf<2> { typedef Emit32 type; };
+template <> struct AuxEmitOf<3> { typedef PairEmit32 type; };
+template <int MODE>
 __global__ __launch_bounds__(BS) void k_aux(AuxArgs A, size_t first) {
-    size_t i = lane_sig<WIDE>(first);
-    if (WIDE) {
-        body_aux<PairEmit>(A, (int)blockIdx.y, i);
-    } else if (i < A.n) {
-        body_aux<Emit>(A, (int)blockIdx.y, i);
-    }
+    size_t i = lane_sig<(MODE & 1) != 0>(first);
+    if ((MODE & 1) || i < A.n) body_aux<typename AuxEmitOf<MODE>::type>(A, (int)blockIdx.y, i);
 }
 // err words -> caller's err bytes, valid bytes, flagged count
 __global__ __launch_bounds__(BS) void k_finalize(const u32* err32, const uint8_t* valid8, uint8_t* err_out,
@@ -1136,6 +1138,42 @@ extern "C" long p2e_columns_compact(p2e_ctx* c, int program, const uint64_t* col
     return S.done(finish_call(c));
 }
 
+// aux_u32: the output matrix is u32 (all values are limbs, bits and flags); cols == nullptr: read the compact
+// container's narrow matrix instead of the u64 witness matrix
+static long run_aux(p2e_ctx* c, int program, const uint8_t* pky32, const uint64_t* cols, size_t ld, const uint32_t* narrow,
+                    size_t ldn, void* aux, bool aux_u32, size_t ld_aux, size_t n, uint8_t* err) {
+    const DeviceProgram& DP = c->progs[program];
+    Staged S(c);
+    pky32 = S.in(pky32, 32 * n);
+    if (cols) cols = S.in(cols, (size_t)DP.prog.num_cols * ld * 8);
+    if (narrow) narrow = S.in(narrow, (size_t)DP.num_narrow * ldn * 4);
+    aux = S.out((char*)aux, (size_t)DP.aux_tab.num_aux_cols * ld_aux * (aux_u32 ? 4 : 8));
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    if (int rc = ensure_scratch(c, n * sizeof(u32))) return S.done(rc);
+    ZERO_COUNTER(c);
+    u32* err32 = (u32*)c->scratch;
+    HIP_TRY(hipMemsetAsync(err32, 0, n * sizeof(u32), c->stream));
+    AuxArgs A{cols, ld, aux, ld_aux, n, pky32, c->d_cpts, c->d_fbtab, DP.d_aux_items, DP.d_aux_tab, err32,
+              narrow, ldn, DP.d_wide_before};
+    const unsigned gx = (unsigned)((n + BS - 1) / BS), items = (unsigned)DP.aux_items.size();
+    // paired column stores for the full workgroups, one element per lane for the ragged tail
+    const bool wide_ok = (ld_aux % 2 == 0) && ((reinterpret_cast<uintptr_t>(aux) & (aux_u32 ? 7 : 15)) == 0) &&
+                         !getenv("P2E_NARROW_STORES");
+    const size_t n_wide = wide_ok ? (n / BS) * BS : 0;
+    const dim3 gw((unsigned)(n_wide / BS), items), gt((unsigned)((n - n_wide + BS - 1) / BS), items);
+    if (aux_u32) {
+        if (n_wide) hipLaunchKernelGGL(k_aux<3>, gw, dim3(BS), 0, c->stream, A, (size_t)0);
+        if (n > n_wide) hipLaunchKernelGGL(k_aux<2>, gt, dim3(BS), 0, c->stream, A, n_wide);
+    } else {
+        if (n_wide) hipLaunchKernelGGL(k_aux<1>, gw, dim3(BS), 0, c->stream, A, (size_t)0);
+        if (n > n_wide) hipLaunchKernelGGL(k_aux<0>, gt, dim3(BS), 0, c->stream, A, n_wide);
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, err32, (const uint8_t*)nullptr, err,
+                       (uint8_t*)nullptr, n, c->d_counter);
+    c->have_phases = false;
+    return S.done(finish_call(c));
+}
 extern "C" long p2e_aux_witness_batch(p2e_ctx* c, int program, const uint8_t* pky32, const uint64_t* cols, size_t ld,
                                       uint64_t* aux, size_t ld_aux, size_t n, uint8_t* err) {
     if (bad_common(c, n, ld) || program < 0 || program > 1 || !pky32 || !cols || !aux || !err || ld_aux < n) {
@@ -1143,29 +1181,16 @@ extern "C" long p2e_aux_witness_batch(p2e_ctx* c, int program, const uint8_t* pk
         return P2E_E_INVALID;
     }
     if (n == 0) return 0;
-    const DeviceProgram& DP = c->progs[program];
-    Staged S(c);
-    pky32 = S.in(pky32, 32 * n);
-    cols = S.in(cols, (size_t)DP.prog.num_cols * ld * 8);
-    aux = S.out(aux, (size_t)DP.aux_tab.num_aux_cols * ld_aux * 8);
-    err = S.out(err, n);
-    if (S.rc) return S.done(S.rc);
-    if (int rc = ensure_scratch(c, n * sizeof(u32))) return S.done(rc);
-    ZERO_COUNTER(c);
-    u32* err32 = (u32*)c->scratch;
-    HIP_TRY(hipMemsetAsync(err32, 0, n * sizeof(u32), c->stream));
-    AuxArgs A{cols, ld, aux, ld_aux, n, pky32, c->d_cpts, c->d_fbtab, DP.d_aux_items, DP.d_aux_tab, err32};
-    const unsigned gx = (unsigned)((n + BS - 1) / BS), items = (unsigned)DP.aux_items.size();
-    // 16-byte paired column stores for the full workgroups (PairEmit), 8-byte ones for the ragged tail
-    const bool wide_ok = (ld_aux % 2 == 0) && ((reinterpret_cast<uintptr_t>(aux) & 15) == 0) && !getenv("P2E_NARROW_STORES");
-    const size_t n_wide = wide_ok ? (n / BS) * BS : 0;
-    if (n_wide) hipLaunchKernelGGL(k_aux<true>, dim3((unsigned)(n_wide / BS), items), dim3(BS), 0, c->stream, A, (size_t)0);
-    if (n > n_wide)
-        hipLaunchKernelGGL(k_aux<false>, dim3((unsigned)((n - n_wide + BS - 1) / BS), items), dim3(BS), 0, c->stream, A, n_wide);
-    hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, err32, (const uint8_t*)nullptr, err,
-                       (uint8_t*)nullptr, n, c->d_counter);
-    c->have_phases = false;
-    return S.done(finish_call(c));
+    return run_aux(c, program, pky32, cols, ld, nullptr, 0, aux, false, ld_aux, n, err);
+}
+extern "C" long p2e_aux_witness_compact_batch(p2e_ctx* c, int program, const uint8_t* pky32, const uint32_t* narrow,
+                                              size_t ld_narrow, uint32_t* aux32, size_t ld_aux, size_t n, uint8_t* err) {
+    if (bad_common(c, n, ld_narrow) || program < 0 || program > 1 || !pky32 || !narrow || !aux32 || !err || ld_aux < n) {
+        if (c && ld_aux < n) set_error("ld_aux < n");
+        return P2E_E_INVALID;
+    }
+    if (n == 0) return 0;
+    return run_aux(c, program, pky32, nullptr, 0, narrow, ld_narrow, aux32, true, ld_aux, n, err);
 }
 
 // ====================================================================================================

@@ -36,6 +36,7 @@ struct Sink {
 // put_wide / put_wide_at / skip_wide mark the values that need all 64 bits (check_sum, carries): the same
 // stream here, a separate matrix in the compact emitters below.
 struct Emit {
+    typedef u64 elem;
     u64* p;      // &out[col * ld + sig]
     size_t ld;   // column stride in elements
     P2E_HD static Emit at(u64* out, size_t ld_, size_t sig, u32 col) {
@@ -55,6 +56,23 @@ struct Emit {
     P2E_HD void put_wide(u64 v) { put(v); }
     P2E_HD void put_wide_at(int k, u64 v) { put_at(k, v); }
     P2E_HD void skip_wide(int k) { skip(k); }
+    P2E_HD void flush() {}
+};
+// a u32 column matrix (values known to fit: the built-in-generator columns of aux.hpp)
+struct Emit32 {
+    typedef u32 elem;
+    u32* p;
+    size_t ld;
+    P2E_HD static Emit32 at(u32* out, size_t ld_, size_t sig, u32 col) {
+        Emit32 e;
+        e.p = out + (size_t)col * ld_ + sig;
+        e.ld = ld_;
+        return e;
+    }
+    P2E_HD void put(u64 v) {
+        *p = (u32)v;
+        p += ld;
+    }
     P2E_HD void flush() {}
 };
 // the same for the compact container: 4-byte stores into the narrow matrix, 8-byte stores into the wide one
@@ -181,6 +199,7 @@ struct PStream {
 };
 // u64 column matrix, 16-byte stores
 struct PairEmit {
+    typedef u64 elem;
     PStream<u64> s;
     P2E_HD static PairEmit at(u64* out, size_t ld_, size_t sig_, u32 col0) {
         PairEmit e;
@@ -194,6 +213,18 @@ struct PairEmit {
     P2E_HD void put_wide(u64 v) { s.put(v); }
     P2E_HD void put_wide_at(int k, u64 v) { s.put_at(k, v); }
     P2E_HD void skip_wide(int k) { s.skip(k); }
+    P2E_HD void flush() { s.flush(); }
+};
+// u32 column matrix, 8-byte stores of two u32
+struct PairEmit32 {
+    typedef u32 elem;
+    PStream<u32> s;
+    P2E_HD static PairEmit32 at(u32* out, size_t ld_, size_t sig_, u32 col0) {
+        PairEmit32 e;
+        e.s = PStream<u32>::at(out + (size_t)col0 * ld_, ld_, sig_);
+        return e;
+    }
+    P2E_HD void put(u64 v) { s.put((u32)v); }
     P2E_HD void flush() { s.flush(); }
 };
 // compact container: 8-byte stores of two u32 into the narrow matrix, 16-byte stores into the wide one
@@ -219,6 +250,7 @@ struct CompactPairEmit {
 #else
 typedef Emit PairEmit;   // host passes only parse the kernels that name them
 typedef CompactEmit CompactPairEmit;
+typedef Emit32 PairEmit32;
 #endif
 
 template <class E>

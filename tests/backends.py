@@ -50,7 +50,7 @@ class EmuBackend:
         self.L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libp2e_emu.so"))
         for f in ("emu_verify", "emu_glv_mul", "emu_mul", "emu_checksum", "emu_add", "emu_sub", "emu_add_many",
                   "emu_inv", "emu_glv", "emu_split", "emu_pack", "emu_aux", "emu_aux_num_cols", "emu_verify_compact",
-                  "emu_glv_mul_compact"):
+                  "emu_glv_mul_compact", "emu_aux_compact"):
             getattr(self.L, f).restype = C.c_long
 
     def mul(self, field, x, y):
@@ -160,6 +160,18 @@ def _emu_compact(self, program, inputs, nn, nw, run_iters=4):
 
 
 EmuBackend.compact = _emu_compact
+
+
+def _emu_aux_compact(self, program, pky, narrow):
+    n = narrow.shape[1]
+    aux = np.zeros((int(self.L.emu_aux_num_cols(C.c_int(program))), n), np.uint32)
+    err = np.zeros(n, np.uint8)
+    pky = np.ascontiguousarray(pky, np.uint8)
+    self.L.emu_aux_compact(C.c_int(program), _p(pky), _p(narrow), C.c_size_t(n), _p(aux), C.c_size_t(n), C.c_size_t(n), _p(err))
+    return aux, err
+
+
+EmuBackend.aux_compact = _emu_aux_compact
 
 
 class GpuBackend:

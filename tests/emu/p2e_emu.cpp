@@ -211,10 +211,38 @@ long emu_aux(int program, const uint8_t* pky, const uint64_t* cols, size_t ld, u
         sb.glv_mul_circuit();
     const host::Consts& C = host::consts();
     std::vector<u32> err32(n);
-    AuxArgs A{cols, ld, aux, ald, n, pky, C.cpts, C.fbtab.data(), sb.aux_items.data(), &sb.aux_tab, err32.data()};
+    AuxArgs A{cols, ld, aux, ald, n, pky, C.cpts, C.fbtab.data(), sb.aux_items.data(), &sb.aux_tab, err32.data(),
+              nullptr, 0, nullptr};
     for (int item = 0; item < (int)sb.aux_items.size(); item++) {
 #pragma omp parallel for
         for (long long i = 0; i < (long long)n; i++) body_aux<Emit>(A, item, (size_t)i);
+    }
+    long bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        err[i] = (uint8_t)err32[i];
+        bad += err32[i] != 0;
+    }
+    return bad;
+}
+// the same pass inside the compact container: narrow u32 matrix in, u32 aux matrix out
+long emu_aux_compact(int program, const uint8_t* pky, const uint32_t* narrow, size_t ldn, uint32_t* aux32, size_t ald, size_t n,
+                     uint8_t* err) {
+    host::ScheduleBuilder sb;
+    if (program == 0)
+        sb.verify_secp256k1_message_circuit();
+    else
+        sb.glv_mul_circuit();
+    const host::Consts& C = host::consts();
+    std::vector<u32> wide_before((size_t)sb.prog.num_cols + 1, 0);
+    for (const auto& g : sb.gens)
+        for (u32 k = 0; k < g.ncols; k++) wide_before[g.col + k + 1] = (g.kind == host::GEN_MUL && k >= 2 * NL) ? 1u : 0u;
+    for (size_t c2 = 1; c2 < wide_before.size(); c2++) wide_before[c2] += wide_before[c2 - 1];
+    std::vector<u32> err32(n);
+    AuxArgs A{nullptr, 0, aux32, ald, n, pky, C.cpts, C.fbtab.data(), sb.aux_items.data(), &sb.aux_tab, err32.data(),
+              narrow, ldn, wide_before.data()};
+    for (int item = 0; item < (int)sb.aux_items.size(); item++) {
+#pragma omp parallel for
+        for (long long i = 0; i < (long long)n; i++) body_aux<Emit32>(A, item, (size_t)i);
     }
     long bad = 0;
     for (size_t i = 0; i < n; i++) {

@@ -290,6 +290,12 @@ def test_fused_compact_output_matches_oracle(ora, monkeypatch, runs):
     got = p2e.compact_expand(0, nar[:, :n].cpu().numpy().view(np.uint32), wid[:, :n].cpu().numpy())
     assert np.array_equal(got, want)
     assert bool((nar[:, n:] == -1).all()) and bool((wid[:, n:] == -1).all())
+    # the built-in-generator pass inside the container: narrow matrix in, u32 matrix out
+    aux32 = torch.full((p2e.VERIFY_AUX_COLS, n + 6), -1, dtype=torch.int32, device="cuda")
+    _, aerr, abad = ctx.aux_witness_compact_batch(0, dev[4], nar, n=n, ld_narrow=n + 2, aux32=aux32, ld_aux=n + 6)
+    torch.cuda.synchronize()
+    assert abad == 0 and bool((aux32[:, n:] == -1).all())
+    assert np.array_equal(aux32[:, :n].cpu().numpy().view(np.uint32).astype(np.uint64), ora.aux(0, sigs)[1])
     # and it is the same container p2e_columns_compact makes from the standard matrix
     cols, _, _, _ = ctx.ecdsa_verify_witness_batch(*dev)
     nar2, wid2, _, _ = ctx.columns_compact(0, cols, n=n, ld=cols.stride(0))

@@ -119,6 +119,9 @@ def test_compact_emitter_bodies_match_the_oracle(program):
     narrow, wide, err, _valid = emu.compact(program, inputs, nn, nw)
     assert not err.any()
     assert np.array_equal(p2e.compact_expand(program, narrow, wide), want)
+    # the built-in-generator pass inside the container: narrow matrix in, u32 matrix out
+    aux32, aerr = emu.aux_compact(program, inputs[4] if program == 0 else inputs[1], narrow)
+    assert not aerr.any() and np.array_equal(aux32.astype(np.uint64), ora.aux(program, inputs)[1])
 
 
 def test_synth_signatures_restates_sign_message():
