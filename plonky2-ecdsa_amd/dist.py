@@ -57,3 +57,21 @@ def global_column(gathered, col: int, total: int):
         s, e = shard_bounds(total, r, world)
         parts.append(gathered[r, col, : e - s])
     return torch.cat(parts)
+
+
+def all_gather_compact(narrow, wide, total: int, group=None):
+    """The same assembly for the compact container (include/p2e.h p2e_columns_compact): two collectives, one per
+    matrix, 28 % fewer bytes over xGMI than the u64 matrix.  Returns (world, num_narrow, n_max) int32 and
+    (world, num_wide, n_max) int64."""
+    return all_gather_columns(narrow, total, group), all_gather_columns(wide, total, group)
+
+
+def global_column_compact(gathered_narrow, gathered_wide, col_map, col: int, total: int):
+    """Column ``col`` of the assembled witness from the gathered compact container, widened to int64: (total,).
+    ``col_map`` is plonky2_ecdsa_amd.compact_layout(program)[0]."""
+    import torch
+
+    m = int(col_map[col])
+    if m & 0x80000000:
+        return global_column(gathered_wide, m & 0x7FFFFFFF, total)
+    return global_column(gathered_narrow, m, total).to(torch.int64) & 0xFFFFFFFF

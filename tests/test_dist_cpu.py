@@ -47,6 +47,15 @@ def _worker(rank, world, port, total, q):
         for j in range(total):
             r, i = pd.shard_of(j, total, world)
             ok = ok and np.array_equal(gathered[r, :, i].numpy().view(np.uint64), want[:, j])
+    # the same assembly in the compact container (u32 narrow + u64 wide matrices)
+    cmap, nn, nw = p2e.compact_layout(0)
+    narrow, wide, cerr, _ = EmuBackend().compact(0, sigs, nn, nw)
+    gn, gw = pd.all_gather_compact(torch.from_numpy(narrow.view(np.int32)), torch.from_numpy(wide.view(np.int64)), total)
+    assert not cerr.any() and gn.shape == (world, nn, -(-total // world)) and gw.shape[1] == nw
+    if rank == 0:
+        for c in (0, 17, 18, 50, 344, 17141, 50000, 82614):     # limbs, check_sum and carry columns
+            got = pd.global_column_compact(gn, gw, cmap, c, total).numpy().view(np.uint64)
+            ok = ok and np.array_equal(got, want[c])
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, bool(ok)))
