@@ -187,6 +187,12 @@ long p2e_glv_mul_witness_compact_batch(p2e_ctx *ctx, const uint8_t *px32, const 
                                        uint32_t *narrow, size_t ld_narrow, uint64_t *wide, size_t ld_wide, size_t n,
                                        uint8_t *err, uint8_t *valid);
 
+/* p2e_columns_to_rows for the compact container: one contiguous run of num_narrow u32 and one of num_wide u64 per
+ * signature (rows_narrow[n][row_ld_narrow], rows_wide[n][row_ld_wide]). */
+long p2e_compact_to_rows(p2e_ctx *ctx, int program, const uint32_t *narrow, size_t ld_narrow, const uint64_t *wide,
+                         size_t ld_wide, size_t n, uint32_t *rows_narrow, size_t row_ld_narrow, uint64_t *rows_wide,
+                         size_t row_ld_wide);
+
 /* ---- schedule description (column -> generator map, host only, no GPU needed) ---------------------- */
 typedef struct p2e_gen_desc {
     int32_t kind;  /* 0 add, 1 sub, 2 add_many, 3 mul(+checksum), 4 inv, 5 glv_decomposition */

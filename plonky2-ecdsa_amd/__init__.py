@@ -49,7 +49,7 @@ EXPORTS = (
     "p2e_schedule_describe",
     "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
     "p2e_compact_layout", "p2e_columns_compact", "p2e_ecdsa_verify_witness_compact_batch",
-    "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch",
+    "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch", "p2e_compact_to_rows",
 )
 
 
@@ -103,7 +103,7 @@ def lib():
         for name in EXPORTS:
             if name.endswith("_batch") or name in ("p2e_limb_split", "p2e_limb_pack", "p2e_columns_to_rows", "p2e_schedule_describe",
                                                    "p2e_schedule_num_cols", "p2e_aux_describe", "p2e_aux_num_cols", "p2e_compact_layout",
-                                                   "p2e_columns_compact"):
+                                                   "p2e_columns_compact", "p2e_compact_to_rows"):
                 getattr(_lib, name).restype = C.c_long
     return _lib
 
@@ -331,6 +331,23 @@ class Context:
         self._check(self._L.p2e_columns_to_rows(self._h, _ptr(cols), C.c_size_t(ld), C.c_size_t(n), C.c_size_t(ncols),
                                                 _ptr(rows), C.c_size_t(self._shape(rows)[1])))
         return rows
+
+    def compact_to_rows(self, program, narrow, wide, n, ld_narrow=None, ld_wide=None, rows_narrow=None, rows_wide=None):
+        """columns_to_rows for the compact container: ((n, num_narrow) u32, (n, num_wide) u64), one contiguous witness per signature."""
+        _m, nn, nw = compact_layout(program)
+        if rows_narrow is None or rows_wide is None:
+            if self.host_pointers:
+                rows_narrow, rows_wide = np.zeros((n, nn), dtype=np.uint32), np.zeros((n, nw), dtype=np.uint64)
+            else:
+                import torch
+                dev = f"cuda:{self.device}"
+                rows_narrow = torch.empty((n, nn), dtype=torch.int32, device=dev)
+                rows_wide = torch.empty((n, nw), dtype=torch.int64, device=dev)
+        self._check(self._L.p2e_compact_to_rows(self._h, C.c_int(program), _ptr(narrow), C.c_size_t(ld_narrow or self._shape(narrow)[1]),
+                                                _ptr(wide), C.c_size_t(ld_wide or self._shape(wide)[1]), C.c_size_t(n),
+                                                _ptr(rows_narrow), C.c_size_t(self._shape(rows_narrow)[1]), _ptr(rows_wide),
+                                                C.c_size_t(self._shape(rows_wide)[1])))
+        return rows_narrow, rows_wide
 
     # ---- fused schedules -----------------------------------------------------------------------------
     def ecdsa_verify_witness_batch(self, msg, r, s, pkx, pky, cols=None, err=None, valid=None, ld=None):

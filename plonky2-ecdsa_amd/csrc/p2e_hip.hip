@@ -222,9 +222,10 @@ __global__ __launch_bounds__(BS) void k_pack(const u64* limbs, uint8_t* packed, 
 // Column-major witness matrix -> one contiguous row per signature (what a per-signature PartialWitness
 // fill wants to read): 64 x 64 u64 tiles through LDS, both global sides coalesced 512-byte runs.
 // Rows of the tile are padded to 65 elements so the transposed read walks distinct banks.
-__global__ __launch_bounds__(BS) void k_transpose(const u64* __restrict__ cols, size_t ld, size_t n, size_t ncols,
-                                                  u64* __restrict__ rows, size_t row_ld) {
-    __shared__ u64 tile[64][65];
+template <class T>
+__global__ __launch_bounds__(BS) void k_transpose(const T* __restrict__ cols, size_t ld, size_t n, size_t ncols,
+                                                  T* __restrict__ rows, size_t row_ld) {
+    __shared__ T tile[64][65];
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t s0 = (size_t)blockIdx.x * 64, c0 = (size_t)blockIdx.y * 64;
 #pragma unroll 4
@@ -1104,7 +1105,32 @@ extern "C" long p2e_columns_to_rows(p2e_ctx* c, const uint64_t* cols, size_t ld,
     if (S.rc) return S.done(S.rc);
     ZERO_COUNTER(c);
     dim3 grid((unsigned)((n + 63) / 64), (unsigned)((ncols + 63) / 64));
-    hipLaunchKernelGGL(k_transpose, grid, dim3(BS), 0, c->stream, cols, ld, n, ncols, rows, row_ld);
+    hipLaunchKernelGGL(k_transpose<u64>, grid, dim3(BS), 0, c->stream, cols, ld, n, ncols, rows, row_ld);
+    return S.done(finish_call(c));
+}
+extern "C" long p2e_compact_to_rows(p2e_ctx* c, int program, const uint32_t* narrow, size_t ld_narrow, const uint64_t* wide,
+                                    size_t ld_wide, size_t n, uint32_t* rows_narrow, size_t row_ld_narrow, uint64_t* rows_wide,
+                                    size_t row_ld_wide) {
+    if (bad_common(c, n, ld_narrow) || program < 0 || program > 1 || ld_wide < n || !narrow || !wide || !rows_narrow || !rows_wide)
+        return P2E_E_INVALID;
+    const DeviceProgram& DP = c->progs[program];
+    if (row_ld_narrow < DP.num_narrow || row_ld_wide < DP.num_wide) {
+        set_error("row stride smaller than the matrix");
+        return P2E_E_INVALID;
+    }
+    if (n == 0) return 0;
+    Staged S(c);
+    narrow = S.in(narrow, (size_t)DP.num_narrow * ld_narrow * 4);
+    wide = S.in(wide, (size_t)DP.num_wide * ld_wide * 8);
+    rows_narrow = S.out(rows_narrow, n * row_ld_narrow * 4);
+    rows_wide = S.out(rows_wide, n * row_ld_wide * 8);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    const unsigned gx = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL(k_transpose<u32>, dim3(gx, (DP.num_narrow + 63) / 64), dim3(BS), 0, c->stream, narrow, ld_narrow, n,
+                       (size_t)DP.num_narrow, rows_narrow, row_ld_narrow);
+    hipLaunchKernelGGL(k_transpose<u64>, dim3(gx, (DP.num_wide + 63) / 64), dim3(BS), 0, c->stream, wide, ld_wide, n,
+                       (size_t)DP.num_wide, rows_wide, row_ld_wide);
     return S.done(finish_call(c));
 }
 

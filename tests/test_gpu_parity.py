@@ -296,6 +296,9 @@ def test_fused_compact_output_matches_oracle(ora, monkeypatch, runs):
     torch.cuda.synchronize()
     assert abad == 0 and bool((aux32[:, n:] == -1).all())
     assert np.array_equal(aux32[:, :n].cpu().numpy().view(np.uint32).astype(np.uint64), ora.aux(0, sigs)[1])
+    # one contiguous compact witness per signature
+    rn, rw = ctx.compact_to_rows(0, nar, wid, n, ld_narrow=n + 2, ld_wide=n + 4)
+    assert torch.equal(rn, nar[:, :n].t()) and torch.equal(rw, wid[:, :n].t())
     # and it is the same container p2e_columns_compact makes from the standard matrix
     cols, _, _, _ = ctx.ecdsa_verify_witness_batch(*dev)
     nar2, wid2, _, _ = ctx.columns_compact(0, cols, n=n, ld=cols.stride(0))
