@@ -254,7 +254,7 @@ __global__ __launch_bounds__(BS) void k_compact(const u64* __restrict__ cols, si
     if (i >= n) return;
     const bool two = pair_ok && i + 1 < n;
     const u32 c0 = blockIdx.y * COMPACT_GROUP;
-    u32 bad = 0;
+    u32 bad_a = 0, bad_b = 0;   // high words seen in narrow columns, per signature of the lane
 #pragma unroll 4
     for (u32 k = 0; k < COMPACT_GROUP; k++) {
         const u32 c = c0 + k;
@@ -279,7 +279,8 @@ __global__ __launch_bounds__(BS) void k_compact(const u64* __restrict__ cols, si
                 if (i + 1 < n) dst[1] = b;
             }
         } else {
-            bad |= (u32)(a >> 32) | (u32)(b >> 32);
+            bad_a |= (u32)(a >> 32);
+            bad_b |= (u32)(b >> 32);
             u32* dst = narrow + (size_t)m * ldn + i;
             if (two) {
                 *reinterpret_cast<uint2*>(dst) = make_uint2((u32)a, (u32)b);
@@ -289,10 +290,9 @@ __global__ __launch_bounds__(BS) void k_compact(const u64* __restrict__ cols, si
             }
         }
     }
-    if (bad) {   // a value that does not fit its 32-bit slot: flag both signatures of the lane
-        atomicOr(&err32[i], (u32)ERR_LIMB_RANGE);
-        if (i + 1 < n) atomicOr(&err32[i + 1], (u32)ERR_LIMB_RANGE);
-    }
+    // a value that does not fit its 32-bit slot
+    if (bad_a) atomicOr(&err32[i], (u32)ERR_LIMB_RANGE);
+    if (bad_b) atomicOr(&err32[i + 1], (u32)ERR_LIMB_RANGE);
 }
 
 // ====================================================================================================

@@ -264,7 +264,7 @@ def test_columns_compact_round_trip(n, pad):
     big[7, 5] = 1 << 32                                                             # r limb of the first mul: narrow
     _, _, cerr, cbad = ctx.columns_compact(0, big, n=n, ld=ld, narrow=nar, wide=wid, ld_narrow=n + 2 * pad, ld_wide=n + 4 * pad)
     flagged = np.nonzero(cerr.cpu().numpy())[0].tolist()
-    assert cbad == len(flagged) and 5 in flagged and set(flagged) <= {4, 5}
+    assert cbad == 1 and flagged == [5]
 
 
 @pytest.mark.parametrize("runs", [False, True], ids=["op_by_op", "run_expansion"])
