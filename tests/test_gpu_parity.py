@@ -312,6 +312,16 @@ def test_fused_compact_output_matches_oracle(ora, monkeypatch, runs):
     assert np.array_equal(p2e.compact_expand(1, gn, gw), ora.glv_mul(sigs[3], sigs[4], k)[0])
 
 
+def test_plain_c_client(tmp_path):
+    """examples/fill_batch.c: a C11 program on the C ABI alone (no torch, no Python in the process)."""
+    import subprocess
+    from test_host import _build_c_example
+    exe, env = _build_c_example(tmp_path)
+    r = subprocess.run([exe, "300"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "300 fills x 82615 columns, 0 flagged, 300 signatures verify" in r.stdout
+
+
 def test_api_misuse_returns_status_not_crash():
     import plonky2_ecdsa_amd as p2e
     ctx = p2e.Context(device=0, host_pointers=True)

@@ -124,6 +124,30 @@ def test_compact_emitter_bodies_match_the_oracle(program):
     assert not aerr.any() and np.array_equal(aux32.astype(np.uint64), ora.aux(program, inputs)[1])
 
 
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "fill_batch")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "fill_batch.c"), "-L", os.path.join(ROOT, "plonky2-ecdsa_amd"),
+                           "-lp2e_hip", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "plonky2-ecdsa_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""),
+               GPU_MAX_HW_QUEUES="8")
+    return exe, env
+
+
+def test_plain_c_client_builds_against_the_header_and_fails_loudly_without_a_gpu(tmp_path):
+    """include/p2e.h is plain C; a C client links against the C ABI; with no GPU it gets an error, not a CPU path."""
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(ROOT, "include", "p2e.h")])
+    exe, env = _build_c_example(tmp_path)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by the GPU suite")
+    r = subprocess.run([exe, "8"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "no CPU fallback" in r.stderr
+
+
 def test_synth_signatures_restates_sign_message():
     arrs = p2e.synth_signatures(seed=9, n=4, first=2)
     for i in range(4):
