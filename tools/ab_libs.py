@@ -33,11 +33,11 @@ def step(L, h):
         rc = L.p2e_glv_mul_witness_batch(h, C.c_void_p(dev[3].data_ptr()), C.c_void_p(dev[4].data_ptr()), C.c_void_p(dev[0].data_ptr()),
                                          C.c_void_p(big.data_ptr()), C.c_size_t(n), C.c_size_t(ld), C.c_void_p(err.data_ptr()),
                                          C.c_void_p(valid.data_ptr()))
-        assert rc == 0, rc
+        assert rc >= 0, rc
         return
     rc = L.p2e_ecdsa_verify_witness_batch(h, *[C.c_void_p(d.data_ptr()) for d in dev], C.c_void_p(big.data_ptr()), C.c_size_t(n), C.c_size_t(ld),
                                           C.c_void_p(err.data_ptr()), C.c_void_p(valid.data_ptr()))
-    assert rc == 0, rc
+    assert rc >= 0, rc
 res = {p: [] for p in libs}
 for L, h in ctxs:
     step(L, h); step(L, h)
