@@ -121,6 +121,11 @@ long p2e_limb_pack(p2e_ctx *ctx, const uint64_t *limbs, uint8_t *packed, size_t 
 long p2e_ecdsa_verify_witness_batch(p2e_ctx *ctx, const uint8_t *msg32, const uint8_t *r32, const uint8_t *s32,
                                     const uint8_t *pkx32, const uint8_t *pky32, uint64_t *cols, size_t n,
                                     size_t ld, uint8_t *err, uint8_t *valid);
+/* The same circuit evaluated for its verdict only (a pre-filter for invalid signatures before
+ * the witness is worth filling; curve/ecdsa.rs:42-62 verify_message on the GPU): valid[i] and err[i] exactly as
+ * p2e_ecdsa_verify_witness_batch would set them, no columns written. */
+long p2e_ecdsa_verify_batch(p2e_ctx *ctx, const uint8_t *msg32, const uint8_t *r32, const uint8_t *s32,
+                            const uint8_t *pkx32, const uint8_t *pky32, size_t n, uint8_t *err, uint8_t *valid);
 /* glv_mul(p, k) gadgets/glv.rs:87-104: cols[P2E_GLV_MUL_COLS][ld]. */
 long p2e_glv_mul_witness_batch(p2e_ctx *ctx, const uint8_t *px32, const uint8_t *py32, const uint8_t *k32,
                                uint64_t *cols, size_t n, size_t ld, uint8_t *err, uint8_t *valid);

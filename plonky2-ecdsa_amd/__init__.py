@@ -49,7 +49,7 @@ EXPORTS = (
     "p2e_schedule_describe",
     "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
     "p2e_compact_layout", "p2e_columns_compact", "p2e_ecdsa_verify_witness_compact_batch",
-    "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch", "p2e_compact_to_rows",
+    "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch", "p2e_compact_to_rows", "p2e_ecdsa_verify_batch",
 )
 
 
@@ -398,6 +398,15 @@ class Context:
                                                       _ptr(narrow), C.c_size_t(ld_narrow or self._shape(narrow)[1]), _ptr(wide),
                                                       C.c_size_t(ld_wide or self._shape(wide)[1]), _ptr(err)))
         return narrow, wide, err, bad
+
+    def ecdsa_verify_batch(self, msg, r, s, pkx, pky, err=None, valid=None):
+        """The verdict alone (pre-filter, no witness): (err, valid, flagged count), as ecdsa_verify_witness_batch sets them."""
+        n = self._shape(msg)[0]
+        err = err if err is not None else self._vec(n, np.uint8)
+        valid = valid if valid is not None else self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_ecdsa_verify_batch(self._h, _ptr(msg), _ptr(r), _ptr(s), _ptr(pkx), _ptr(pky),
+                                                         C.c_size_t(n), _ptr(err), _ptr(valid)))
+        return err, valid, bad
 
     def _compact_out(self, program, n, narrow, wide, ld_narrow, ld_wide):
         _m, nn, nw = compact_layout(program)

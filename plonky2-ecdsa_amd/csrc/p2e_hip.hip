@@ -42,6 +42,7 @@ template <> struct EmitOf<0> { typedef Emit type; };
 template <> struct EmitOf<1> { typedef PairEmit type; };
 template <> struct EmitOf<2> { typedef CompactEmit type; };
 template <> struct EmitOf<3> { typedef CompactPairEmit type; };
+template <> struct EmitOf<4> { typedef NullEmit type; };   // no witness: p2e_ecdsa_verify_batch
 template <int MODE>
 __global__ __launch_bounds__(BS) void k_scalar(Program G, Buffers B, size_t first) {
     size_t i = lane_sig<(MODE & 1) != 0>(first);
@@ -79,6 +80,12 @@ __global__ __launch_bounds__(BS) void k_expand_runs(Program G, Buffers B, int it
     int it0 = it_first + (int)blockIdx.y * run_iters;
     int it1 = it0 + run_iters < it_end ? it0 + run_iters : it_end;
     if ((MODE & 1) || i < B.n) body_expand_run<typename EmitOf<MODE>::type>(G, B, i, it0, it1);
+}
+// p2e_ecdsa_verify_batch: the connect r == x of gadgets/ecdsa.rs:48-52 on the final add's Jacobian result, without an
+// inversion: x = X / Z^2 is canonical, so x == r  <=>  r < p and X == r * Z^2 (Z != 0, else phase A flagged the element)
+__global__ __launch_bounds__(BS) void k_verify_check(Program G, Buffers B) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    if (i < B.n) body_verify_check(G, B, i);
 }
 // built-in-generator columns from the finished witness matrix: one (signature, item) per lane (aux.hpp)
 // MODE bit 0 = paired stores over full workgroups, bit 1 = u32 output matrix
@@ -837,8 +844,9 @@ extern "C" long p2e_limb_pack(p2e_ctx* c, const uint64_t* limbs, uint8_t* packed
 // cols != nullptr: the u64 column matrix; otherwise the compact container (narrow, wide)
 static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8_t* r, const uint8_t* s,
                         const uint8_t* pkx, const uint8_t* pky, uint64_t* cols, size_t n, size_t ld, uint8_t* err,
-                        uint8_t* valid, uint32_t* narrow = nullptr, size_t ldn = 0, uint64_t* wide = nullptr, size_t ldw = 0) {
-    const bool compact = cols == nullptr;
+                        uint8_t* valid, uint32_t* narrow = nullptr, size_t ldn = 0, uint64_t* wide = nullptr, size_t ldw = 0,
+                        bool verify_only = false) {
+    const bool compact = cols == nullptr && !verify_only;
     const DeviceProgram& DP = c->progs[program];
     const Program& G = DP.prog;
     Staged S(c);
@@ -850,7 +858,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     if (compact) {
         narrow = S.out(narrow, (size_t)DP.num_narrow * ldn * 4);
         wide = S.out(wide, (size_t)DP.num_wide * ldw * 8);
-    } else {
+    } else if (!verify_only) {
         cols = S.out(cols, (size_t)G.num_cols * ld * 8);
     }
     err = S.out(err, n);
@@ -888,6 +896,23 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     ZERO_COUNTER(c);
     unsigned gx = (unsigned)((n + BS - 1) / BS);
     c->n_expand = 0;
+    if (verify_only) {
+        // the native verification alone: scalar phase without emission, the two chains side by side in Jacobian
+        // coordinates (no batch inversion, no expansion), the final add, r == x on its Jacobian result
+        B.ops = DP.d_ops_plain;
+        hipLaunchKernelGGL(k_scalar<4>, dim3(gx), dim3(BS), 0, c->stream, G, B, (size_t)0);
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->st_fixed, c->ev_fork, 0));
+        hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, c->st_fixed, G, B, G.chain_begin[1], G.chain_end[1], 0, 0);
+        HIP_TRY(hipEventRecord(c->ev_fixed, c->st_fixed));
+        hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, c->stream, G, B, G.chain_begin[0], G.chain_end[0], 0, 0);
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fixed, 0));
+        hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, c->stream, G, B, G.chain_begin[2], G.chain_end[2], 0, 0);
+        hipLaunchKernelGGL(k_verify_check, dim3(gx), dim3(BS), 0, c->stream, G, B);
+        hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, B.err, B.valid, err, valid, n, c->d_counter);
+        c->have_phases = false;
+        return S.done(finish_call(c));
+    }
     // 16-byte column stores need full workgroups, an even column stride and a 16-byte aligned matrix
     // paired stores need full workgroups, even column strides and matrices aligned to two elements
     const bool wide_ok = !getenv("P2E_NARROW_STORES") &&
@@ -1071,6 +1096,12 @@ extern "C" long p2e_ecdsa_verify_witness_batch(p2e_ctx* c, const uint8_t* msg32,
     if (bad_common(c, n, ld) || !msg32 || !r32 || !s32 || !pkx32 || !pky32 || !cols || !err) return P2E_E_INVALID;
     if (n == 0) return 0;
     return run_program(c, 0, msg32, r32, s32, pkx32, pky32, cols, n, ld, err, valid);
+}
+extern "C" long p2e_ecdsa_verify_batch(p2e_ctx* c, const uint8_t* msg32, const uint8_t* r32, const uint8_t* s32,
+                                       const uint8_t* pkx32, const uint8_t* pky32, size_t n, uint8_t* err, uint8_t* valid) {
+    if (bad_common(c, n, n) || !msg32 || !r32 || !s32 || !pkx32 || !pky32 || !err || !valid) return P2E_E_INVALID;
+    if (n == 0) return 0;
+    return run_program(c, 0, msg32, r32, s32, pkx32, pky32, nullptr, n, n, err, valid, nullptr, 0, nullptr, 0, true);
 }
 extern "C" long p2e_glv_mul_witness_batch(p2e_ctx* c, const uint8_t* px32, const uint8_t* py32, const uint8_t* k32,
                                           uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid) {

@@ -368,6 +368,15 @@ P2E_HD void body_chain_rows(const Program& G, const Buffers& B, size_t i, int lo
     for (int j = 0; j < count; j++) body_chain_op(G, B, i, lo + row + j * rows, false, st);
 }
 
+// The connect r == x of gadgets/ecdsa.rs:48-52 on the final add's JACOBIAN result (p2e_ecdsa_verify_batch: verdict
+// only, no batch inversion): x = X / Z^2 is canonical, so x == r  <=>  r < p and X == r * Z^2.
+P2E_HD void body_verify_check(const Program& G, const Buffers& B, size_t i) {
+    const size_t o = (size_t)(G.chain_end[2] - 1) * B.n + i;
+    const U256 r = load_packed(B.r, i), X = B.PX[o], Z = B.PZ[o];
+    const bool r_lt_p = !geq_mod<ModP>(r.w);
+    if (!(r_lt_p && !u256_is_zero(Z) && u256_eq(fp_mul(r, fp_sqr(Z)), X))) B.valid[i] = 0;
+}
+
 // ---- phase B: Montgomery batch inversion of Z over ops [t0, t1) of one signature ------------------------
 // Reads the Jacobian results (left intact: later pieces of the chain still consume them), writes the
 // affine points to AX/AY and v^-1 over W.  have_prefix: [t0, t1) is exactly one inversion batch of phase A,

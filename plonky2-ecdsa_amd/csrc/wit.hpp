@@ -58,6 +58,18 @@ struct Emit {
     P2E_HD void skip_wide(int k) { skip(k); }
     P2E_HD void flush() {}
 };
+// discards everything: the value computations that only feed witness columns disappear at compile time
+// (p2e_ecdsa_verify_batch: the native verification as a pre-filter, no witness)
+struct NullEmit {
+    P2E_HD static NullEmit at(const Sink&, size_t, u32) { return NullEmit(); }
+    P2E_HD void put(u64) {}
+    P2E_HD void put_at(int, u64) {}
+    P2E_HD void skip(int) {}
+    P2E_HD void put_wide(u64) {}
+    P2E_HD void put_wide_at(int, u64) {}
+    P2E_HD void skip_wide(int) {}
+    P2E_HD void flush() {}
+};
 // a u32 column matrix (values known to fit: the built-in-generator columns of aux.hpp)
 struct Emit32 {
     typedef u32 elem;

@@ -50,7 +50,7 @@ class EmuBackend:
         self.L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libp2e_emu.so"))
         for f in ("emu_verify", "emu_glv_mul", "emu_mul", "emu_checksum", "emu_add", "emu_sub", "emu_add_many",
                   "emu_inv", "emu_glv", "emu_split", "emu_pack", "emu_aux", "emu_aux_num_cols", "emu_verify_compact",
-                  "emu_glv_mul_compact", "emu_aux_compact"):
+                  "emu_glv_mul_compact", "emu_aux_compact", "emu_verify_only"):
             getattr(self.L, f).restype = C.c_long
 
     def mul(self, field, x, y):
@@ -172,6 +172,17 @@ def _emu_aux_compact(self, program, pky, narrow):
 
 
 EmuBackend.aux_compact = _emu_aux_compact
+
+
+def _emu_verify_only(self, msg, r, s, pkx, pky):
+    arrs = [np.ascontiguousarray(a, np.uint8) for a in (msg, r, s, pkx, pky)]
+    n = arrs[0].shape[0]
+    err, valid = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    self.L.emu_verify_only(*[_p(a) for a in arrs], C.c_size_t(n), _p(err), _p(valid))
+    return err, valid
+
+
+EmuBackend.verify_only = _emu_verify_only
 
 
 class GpuBackend:

@@ -187,6 +187,42 @@ long emu_verify(const uint8_t* msg, const uint8_t* r, const uint8_t* s, const ui
                 uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid, int chunk, int run_iters) {
     return run<Emit>(0, msg, r, s, pkx, pky, cols, n, ld, err, valid, chunk, run_iters);
 }
+// verdict only (p2e_ecdsa_verify_batch): scalar phase without emission, Jacobian chains, r == x on the Jacobian result
+long emu_verify_only(const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx, const uint8_t* pky, size_t n,
+                     uint8_t* err, uint8_t* valid) {
+    host::ScheduleBuilder sb;
+    sb.verify_secp256k1_message_circuit();
+    const Program& G = sb.prog;
+    const host::Consts& C = host::consts();
+    std::vector<U256> PX((size_t)G.num_slots * n), PY((size_t)G.num_slots * n), PZ((size_t)G.num_slots * n),
+        PW((size_t)G.num_ops * n), PREF((size_t)G.num_ops * n), AX((size_t)G.num_slots * n), AY((size_t)G.num_slots * n);
+    std::vector<uint8_t> dig4((size_t)FB_WINDOWS * n), dig2((size_t)MSM_DIGITS * n), valid8(n);
+    std::vector<uint16_t> dyn((size_t)G.num_cadd * n), src((size_t)G.num_ops * 2 * n);
+    std::vector<u32> err32(n);
+    Buffers B{};
+    B.msg = msg; B.r = r; B.s = s; B.pkx = pkx; B.pky = pky;
+    B.n = n;
+    B.err = err32.data(); B.valid = valid8.data();
+    B.PX = PX.data(); B.PY = PY.data(); B.PZ = PZ.data(); B.PW = PW.data(); B.PREF = PREF.data();
+    B.AX = AX.data(); B.AY = AY.data();
+    B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data(); B.src = src.data();
+    B.cpts = C.cpts; B.fbtab = C.fbtab.data(); B.ops = sb.ops.data();
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)n; i++) {
+        body_scalar<NullEmit>(G, B, (size_t)i);
+        body_chain_range(G, B, (size_t)i, G.chain_begin[1], G.chain_end[1], false, false);
+        body_chain_range(G, B, (size_t)i, G.chain_begin[0], G.chain_end[0], false, false);
+        body_chain_range(G, B, (size_t)i, G.chain_begin[2], G.chain_end[2], false, false);
+        body_verify_check(G, B, (size_t)i);
+    }
+    long bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        err[i] = (uint8_t)err32[i];
+        valid[i] = err32[i] ? 0 : valid8[i];
+        bad += err32[i] != 0;
+    }
+    return bad;
+}
 // the same walk writing the compact container directly (CompactEmit: what the compact kernels' ragged tail runs)
 long emu_verify_compact(const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx, const uint8_t* pky,
                         uint32_t* narrow, size_t ldn, uint64_t* wide, size_t ldw, size_t n, uint8_t* err, uint8_t* valid,

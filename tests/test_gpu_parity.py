@@ -312,6 +312,26 @@ def test_fused_compact_output_matches_oracle(ora, monkeypatch, runs):
     assert np.array_equal(p2e.compact_expand(1, gn, gw), ora.glv_mul(sigs[3], sigs[4], k)[0])
 
 
+def test_verdict_only_matches_full_fill(ora):
+    """p2e_ecdsa_verify_batch (pre-filter: no columns written) sets valid / err like the witness fill, on a ragged batch
+    with tampered signatures and an inverse-of-zero element."""
+    import plonky2_ecdsa_amd as p2e
+    n = 333
+    arrs = [a.copy() for a in p2e.synth_signatures(seed=91, n=n)]
+    for i in range(0, n, 5):
+        arrs[i % 3][i, 0] ^= 1                                     # tamper msg / r / s
+    rx, ry = R.rando_point()
+    arrs[3][17] = np.frombuffer(int(rx).to_bytes(32, "little"), dtype=np.uint8)
+    arrs[4][17] = np.frombuffer(int((-ry) % R.P).to_bytes(32, "little"), dtype=np.uint8)
+    ctx = p2e.Context(device=0, host_pointers=True)
+    _cols, ferr, fvalid, _ = ctx.ecdsa_verify_witness_batch(*arrs)
+    verr, vvalid, vbad = ctx.ecdsa_verify_batch(*arrs)
+    _want, werr, wflags = ora.verify(*arrs)
+    assert np.array_equal(verr != 0, werr != 0) and np.array_equal(verr != 0, ferr != 0) and vbad == int((verr != 0).sum())
+    assert np.array_equal(vvalid, fvalid) and np.array_equal(vvalid[werr == 0], wflags[werr == 0])
+    assert verr[17] & R.ERR_INVERSE_OF_ZERO and 0 < int(vvalid.sum()) < n
+
+
 def test_plain_c_client(tmp_path):
     """examples/fill_batch.c: a C11 program on the C ABI alone (no torch, no Python in the process)."""
     import subprocess

@@ -215,6 +215,30 @@ def test_pipeline_edge_inputs():
     assert np.array_equal(err != 0, werr != 0)
     ok = werr == 0
     assert np.array_equal(got[:, ok], want[:, ok]) and np.array_equal(valid[ok], wflags[ok])
+    # the verdict-only walk (p2e_ecdsa_verify_batch bodies: no emission, no batch inversion) agrees on err and valid
+    verr, vvalid = emu.verify_only(*arrs)
+    assert np.array_equal(verr != 0, err != 0) and np.array_equal(vvalid, valid)
+
+
+def test_verdict_only_bodies_on_mixed_batch():
+    """Valid signatures, tampered r / s / msg / pk, r >= p, and an inverse-of-zero element: the verdict-only walk sets
+    valid and err like the full witness walk (which the oracle checks)."""
+    emu, ora = EmuBackend(), OracleBackend()
+    n = 48
+    sigs = [list(R.synth_signature_at(77, i)) for i in range(n)]
+    rx, ry = R.rando_point()
+    for i in range(0, n, 6):
+        sigs[i][i % 3] = (sigs[i][i % 3] + 1 + i) % R.N           # tamper msg / r / s
+    sigs[7][3], sigs[7][4] = R.GX, R.GY                            # wrong public key
+    sigs[11][1] = R.P + 5                                          # r >= p can never equal a canonical x
+    sigs[13][3], sigs[13][4] = rx, (-ry) % R.P                     # inverse of zero in the window table
+    arrs = [oracle_c.pack256([c[k] for c in sigs]) for k in range(5)]
+    _want, werr, wflags = ora.verify(*arrs)
+    verr, vvalid = emu.verify_only(*arrs)
+    assert np.array_equal(verr != 0, werr != 0) and verr[13] & R.ERR_INVERSE_OF_ZERO
+    ok = werr == 0
+    assert np.array_equal(vvalid[ok], wflags[ok]) and not vvalid[~ok].any()
+    assert vvalid.sum() == n - len(range(0, n, 6)) - 3
 
 
 def test_inverse_of_zero_is_flagged_not_fatal():

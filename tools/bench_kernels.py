@@ -33,7 +33,7 @@ def timed(fn):
     return ts[len(ts) // 2]
 
 
-which = sys.argv[1:] or ["split", "mul", "transpose", "glv", "aux", "compact"]
+which = sys.argv[1:] or ["split", "mul", "transpose", "glv", "aux", "compact", "verdict"]
 if "split" in which:
     for lg in (20, 24, 26):
         n = 1 << lg
@@ -109,3 +109,14 @@ if "compact" in which:
     b = n * (p2e.VERIFY_COLS * 8 + nn * 4 + nw * 8)
     print(json.dumps({"kernel": "k_compact", "n": n, "ms": round(ms, 4), "alg_bytes": b, "GBps": round(b / ms / 1e6, 1),
                       "frac_hbm_peak": round(b / ms / 1e6 / PEAK, 4)}), flush=True)
+if "verdict" in which:
+    # p2e_ecdsa_verify_batch: the verdict alone (scalar phase + Jacobian chains, no witness), the pre-filter of SURVEY 8(f) rank 4
+    n = 1 << 16
+    sig = p2e.synth_signatures(seed=4, n=n)
+    dev = [torch.from_numpy(a).cuda() for a in sig]
+    err = torch.empty(n, dtype=torch.uint8, device="cuda")
+    valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ms = timed(lambda: ctx.ecdsa_verify_batch(*dev, err=err, valid=valid))
+    assert int(valid.sum()) == n
+    print(json.dumps({"kernel": "ecdsa_verify_batch (verdict only)", "n": n, "ms": round(ms, 4),
+                      "verifies_per_s": round(n / ms * 1e3, 1)}), flush=True)
