@@ -46,6 +46,7 @@ extern "C" {
 #define P2E_ERR_VALUE_GE_2_256 2   /* from_noncanonical_biguint panics (template field/p256_base.rs:121-130)  */
 #define P2E_ERR_INVERSE_OF_ZERO 4  /* gadgets/nonnative.rs:863 inverse() of zero                               */
 #define P2E_ERR_CARRY_RANGE 8      /* gates/mul_nonnative.rs:527 carry not < 2^34                              */
+#define P2E_ERR_DIVISION_BY_ZERO 32 /* BigUintDivRemGenerator: b == 0 (BigUint::div_rem panics)                        */
 #define P2E_ERR_QUOTIENT_RANGE 16  /* x*y/m does not fit the gate's nine q wires (x, y far above the modulus)  */
 
 /* status codes (negative returns) */
@@ -105,6 +106,14 @@ long p2e_add_many_witness_batch(p2e_ctx *ctx, int field, const uint64_t *summand
 /* NonNativeInverseGenerator::run_once gadgets/nonnative.rs:857-872: inv[9], div[9]. */
 long p2e_inv_witness_batch(p2e_ctx *ctx, int field, const uint64_t *x, uint64_t *inv, uint64_t *div, size_t n,
                            size_t ld, uint8_t *err);
+/* BigUintDivRemGenerator::run_once gadgets/biguint.rs:508-518 (the generator behind rem_biguint / reduce,
+ * gadgets/nonnative.rs:539-548; not on the ECDSA path, here so that every generator of the crate has an entry):
+ * a[na][ld] (1 <= na <= 18 limbs), b[nb][ld] (1 <= nb <= 9) -> div[max(0, na - nb + 1)][ld], rem[nb][ld], the limb
+ * counts div_rem_biguint allocates (:391-397).  err: a limb >= 2^29 (LIMB_RANGE; the reference would sum arbitrary
+ * field elements), b == 0 (DIVISION_BY_ZERO), a quotient set_biguint_target rejects (LIMB_RANGE; this includes
+ * the reference's convert_base quirk: a D-digit value is handed over as floor(32 D / 29) limbs, zero ones included). */
+long p2e_biguint_div_rem_batch(p2e_ctx *ctx, const uint64_t *a, int na, const uint64_t *b, int nb, uint64_t *div,
+                               uint64_t *rem, size_t n, size_t ld, uint8_t *err);
 /* GLVDecompositionGenerator::run_once gadgets/glv.rs:128-142 (curve/glv.rs:39-77): k1[5], k2[5], signs. */
 long p2e_glv_decompose_batch(p2e_ctx *ctx, const uint64_t *k, uint64_t *k1, uint64_t *k2, uint64_t *k1_neg,
                              uint64_t *k2_neg, size_t n, size_t ld, uint8_t *err);

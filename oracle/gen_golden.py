@@ -127,6 +127,42 @@ def kat_inv(field):
     return out
 
 
+def kat_div_rem():
+    """BigUintDivRemGenerator (gadgets/biguint.rs:508-518) at the shapes rem_biguint / reduce produce and a few odd ones.
+    Inputs are plain 29-bit limb splits (NOT limbs_of: that has the set_biguint_target quirk on the input side)."""
+    def split(v, k):
+        return [(v >> (R.BITS * i)) & ((1 << R.BITS) - 1) for i in range(k)]
+    rng = R.SplitMix64(700)
+
+    def rnd(bits):
+        v = 0
+        for _ in range((bits + 63) // 64):
+            v = (v << 64) | rng.next()
+        return v >> (64 * ((bits + 63) // 64) - bits) if bits else 0
+    out = []
+    for na, nb in ((18, 9), (9, 9), (10, 9), (18, 1), (5, 9), (9, 5), (1, 1), (12, 7)):
+        nd = 0 if nb > na + 1 else na - nb + 1
+        cases = [(rnd(R.BITS * na), R.P if nb == 9 else max(1, rnd(R.BITS * nb))),          # reduce: b = field order
+                 (rnd(R.BITS * na), R.N if nb == 9 else max(1, rnd(R.BITS * nb - 3))),
+                 ((1 << (R.BITS * na)) - 1, 1), ((1 << (R.BITS * na)) - 1, (1 << (R.BITS * nb)) - 1),
+                 (0, 5), (7, 0),                                                                # zero dividend, zero divisor
+                 (rnd(min(R.BITS * na, R.BITS * nb)), max(1, rnd(R.BITS * nb)))]
+        for bits_short in (0, 1, 2, 3, 4):     # quotients around the top of their limbs: the convert_base quirk zone
+            b = max(1, rnd(R.BITS * nb - 5))
+            qv = rnd(max(1, R.BITS * nd - bits_short)) | (1 << max(0, R.BITS * nd - bits_short - 1)) if nd else 0
+            cases.append((min((1 << (R.BITS * na)) - 1, qv * b + (b >> 1)), b))
+        for a, b in cases:
+            al, bl = split(a, na), split(b & ((1 << (R.BITS * nb)) - 1), nb)
+            res, err = run(lambda: R.gen_div_rem(al, bl))
+            out.append({"na": na, "nb": nb, "a": al, "b": bl, "div": res[0] if res else None, "rem": res[1] if res else None,
+                        "err": err})
+    bad = split(12345, 9)
+    bad[2] = 1 << 29                                                                            # a limb out of range
+    res, err = run(lambda: R.gen_div_rem(bad, split(77, 9)))
+    out.append({"na": 9, "nb": 9, "a": bad, "b": split(77, 9), "div": None, "rem": None, "err": err})
+    return out
+
+
 def kat_add_many(field):
     m = R.MODULI[field]
     rng = R.SplitMix64(400 + field)
@@ -191,7 +227,7 @@ def write_gz(path, text):
 def main():
     kats = {"add_sub": kat_add_sub(0) + kat_add_sub(1), "mul": kat_mul(0) + kat_mul(1),
             "inv": kat_inv(0) + kat_inv(1), "add_many": kat_add_many(0) + kat_add_many(1), "glv": kat_glv(),
-            "checksum": kat_checksum()}
+            "checksum": kat_checksum(), "div_rem": kat_div_rem()}
     with open(os.path.join(OUT, "prim_kats.json"), "w") as f:
         json.dump(kats, f, separators=(",", ":"))
 

@@ -33,7 +33,7 @@ def lib():
         _LIB = C.CDLL(path)
         for name in ("mul_witness", "checksum_witness", "add_witness", "sub_witness", "add_many_witness",
                      "inv_witness", "glv_decompose", "limb_split", "limb_pack", "verify_witness",
-                     "glv_mul_witness", "verify_witness_aux", "glv_mul_witness_aux"):
+                     "glv_mul_witness", "verify_witness_aux", "glv_mul_witness_aux", "div_rem"):
             getattr(_LIB, "p2e_oracle_" + name).restype = C.c_long
     return _LIB
 
@@ -133,6 +133,18 @@ def limb_pack(limbs):
     err = np.zeros(n, dtype=np.uint8)
     lib().p2e_oracle_limb_pack(_p(limbs), _p(out), C.c_size_t(n), C.c_size_t(n), _p(err))
     return out, err
+
+
+def div_rem(a, b):
+    """BigUintDivRemGenerator: a (na, n), b (nb, n) limb columns -> (div (max(0, na-nb+1), n), rem (nb, n), err)."""
+    a, b = np.ascontiguousarray(a, dtype=np.uint64), np.ascontiguousarray(b, dtype=np.uint64)
+    na, nb, n = a.shape[0], b.shape[0], a.shape[1]
+    nd = 0 if nb > na + 1 else na - nb + 1
+    div, rem = _cols(max(nd, 1), n), _cols(nb, n)
+    err = np.zeros(n, dtype=np.uint8)
+    rc = lib().p2e_oracle_div_rem(_p(a), C.c_int(na), _p(b), C.c_int(nb), _p(div), _p(rem), C.c_size_t(n), C.c_size_t(n), _p(err))
+    assert rc >= 0
+    return div[:nd], rem, err
 
 
 def verify_witness(msg, r, s, pkx, pky, nthreads=0):

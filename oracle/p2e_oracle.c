@@ -989,6 +989,80 @@ long p2e_oracle_inv_witness(int field, const uint64_t *x, uint64_t *inv, uint64_
     }
     return count_err(err, n);
 }
+/* number of limbs set_biguint_target sees (gadgets/biguint.rs:455-456): convert_base emits floor(32 D / 29) limbs for
+ * the D u32 digits of the value -- zero ones included -- plus one more if bits are left over.  A value can therefore
+ * "not fit" a target it would fit arithmetically (e.g. 289..290 bits into 10 limbs): the reference panics, so do we. */
+static int ref_limb_len(const w32 *w, int nw) {
+    int d = nw;
+    while (d > 0 && w[d - 1] == 0) d--;
+    int l = (32 * d) / BITS;
+    int rest = 0;
+    for (int bit = BITS * l; bit < 32 * d; bit++) rest |= (w[bit >> 5] >> (bit & 31)) & 1;
+    return l + rest;
+}
+long p2e_oracle_div_rem(const uint64_t *a, int na, const uint64_t *b, int nb, uint64_t *div, uint64_t *rem, size_t n,
+                        size_t ld, uint8_t *err) {
+    if (na < 1 || na > 18 || nb < 1 || nb > 9) return -1;
+    const int nd = nb > na + 1 ? 0 : na - nb + 1;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t i = 0; i < n; i++) {
+        u64 al[18], bl[9], dl[18], rl[9];
+        uint8_t e = 0;
+        gather(a, ld, i, al, na);
+        gather(b, ld, i, bl, nb);
+        for (int k = 0; k < na; k++) e |= (al[k] >> BITS) ? P2E_O_ERR_LIMB_RANGE : 0;
+        for (int k = 0; k < nb; k++) e |= (bl[k] >> BITS) ? P2E_O_ERR_LIMB_RANGE : 0;
+        memset(dl, 0, sizeof dl);
+        memset(rl, 0, sizeof rl);
+        if (!e) {
+            /* 29-bit limbs -> 32-bit words (no carries: limbs are in range) */
+            w32 aw[18], bw[10], q[18], r[10];
+            memset(aw, 0, sizeof aw);
+            memset(bw, 0, sizeof bw);
+            for (int k = 0; k < na; k++) {
+                int bit = BITS * k, wi = bit >> 5, sh = bit & 31;
+                u64 v = al[k] << sh;
+                aw[wi] |= (w32)v;
+                if (wi + 1 < 18) aw[wi + 1] |= (w32)(v >> 32);
+            }
+            for (int k = 0; k < nb; k++) {
+                int bit = BITS * k, wi = bit >> 5, sh = bit & 31;
+                u64 v = bl[k] << sh;
+                bw[wi] |= (w32)v;
+                bw[wi + 1] |= (w32)(v >> 32);
+            }
+            int bn = 10;
+            while (bn > 0 && bw[bn - 1] == 0) bn--;
+            if (bn == 0) {
+                e |= P2E_O_ERR_DIVISION_BY_ZERO;
+            } else {
+                memset(q, 0, sizeof q);
+                memset(r, 0, sizeof r);
+                if (bn == 1) { /* short division (bn_divrem needs a divisor of two words or more) */
+                    u64 c = 0;
+                    for (int k = 17; k >= 0; k--) {
+                        c = (c << 32) | aw[k];
+                        q[k] = (w32)(c / bw[0]);
+                        c %= bw[0];
+                    }
+                    r[0] = (w32)c;
+                } else {
+                    bn_divrem(aw, 18, bw, bn, q, r);
+                }
+                if (words_to_limbs(q, 18, dl, nd) || ref_limb_len(q, 18) > nd) e |= P2E_O_ERR_LIMB_RANGE;
+                (void)words_to_limbs(r, 10, rl, nb);
+            }
+        }
+        if (e) {
+            memset(dl, 0, sizeof dl);
+            memset(rl, 0, sizeof rl);
+        }
+        scatter(div, ld, i, dl, nd);
+        scatter(rem, ld, i, rl, nb);
+        err[i] = e;
+    }
+    return count_err(err, n);
+}
 long p2e_oracle_glv_decompose(const uint64_t *k, uint64_t *k1, uint64_t *k2, uint64_t *k1_neg,
                               uint64_t *k2_neg, size_t n, size_t ld, uint8_t *err) {
     oracle_init();

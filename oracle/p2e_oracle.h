@@ -29,6 +29,7 @@ extern "C" {
 #define P2E_O_ERR_INVERSE_OF_ZERO 4
 #define P2E_O_ERR_CARRY_RANGE 8
 #define P2E_O_ERR_QUOTIENT_RANGE 16
+#define P2E_O_ERR_DIVISION_BY_ZERO 32
 
 #define P2E_O_VERIFY_COLS 82615
 #define P2E_O_GLV_MUL_COLS 65243
@@ -56,6 +57,11 @@ long p2e_oracle_inv_witness(int field, const uint64_t *x, uint64_t *inv, uint64_
 /* gadgets/glv.rs:128-142 : k[9][n] -> k1[5][n], k2[5][n], k1_neg[n], k2_neg[n] */
 long p2e_oracle_glv_decompose(const uint64_t *k, uint64_t *k1, uint64_t *k2, uint64_t *k1_neg,
                               uint64_t *k2_neg, size_t n, size_t ld, uint8_t *err);
+/* gadgets/biguint.rs:508-518 BigUintDivRemGenerator: a[na][n] (na <= 18), b[nb][n] (nb <= 9) ->
+ * div[max(0, na - nb + 1)][n], rem[nb][n].  Limbs must be < 2^29 (ERR_LIMB_RANGE), b != 0 (ERR_DIVISION_BY_ZERO),
+ * div must fit its limbs (ERR_LIMB_RANGE: the reference's set_biguint_target assert). */
+long p2e_oracle_div_rem(const uint64_t *a, int na, const uint64_t *b, int nb, uint64_t *div, uint64_t *rem, size_t n,
+                        size_t ld, uint8_t *err);
 /* gadgets/biguint.rs:27-51,454-463 : packed 32-byte LE -> limbs[9][n] and back (pack flags limbs >= 2^29
  * or value >= 2^256) */
 long p2e_oracle_limb_split(const uint8_t *packed, uint64_t *limbs, size_t n, size_t ld);

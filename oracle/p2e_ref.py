@@ -55,6 +55,7 @@ ERR_LIMB_RANGE = 1        # gates/mul_nonnative.rs:262,271,275-276 ; gadgets/big
 ERR_VALUE_GE_2_256 = 2    # Secp256K1*::from_noncanonical_biguint (template field/p256_base.rs:121-130)
 ERR_INVERSE_OF_ZERO = 4   # gadgets/nonnative.rs:863
 ERR_CARRY_RANGE = 8       # gates/mul_nonnative.rs:527
+ERR_DIVISION_BY_ZERO = 32  # BigUint::div_rem by zero panics (BigUintDivRemGenerator)
 ERR_QUOTIENT_RANGE = 16   # q does not fit the gate's nine q wires (documented deviation: flagged, not emitted)
 
 
@@ -277,6 +278,22 @@ def gen_inv(x_limbs, m):
     inv = pow(x, -1, m)
     div = (x * inv) // m
     return limbs_of(inv, k), limbs_of(div, k)
+
+
+def gen_div_rem(a_limbs, b_limbs):
+    """BigUintDivRemGenerator::run_once gadgets/biguint.rs:508-518; output limb counts as div_rem_biguint allocates
+    them (:391-397): div has a_len - b_len + 1 limbs (0 if b_len > a_len + 1), rem has b_len.
+    Deviation of the batch API (all backends): limbs must be proper 29-bit limbs, else ERR_LIMB_RANGE (the reference's
+    get_biguint_target would sum arbitrary field elements)."""
+    if any(l >> BITS for l in list(a_limbs) + list(b_limbs)):
+        raise RefPanic(ERR_LIMB_RANGE, "limb >= 2^29")
+    a, b = value_of(a_limbs), value_of(b_limbs)
+    if b == 0:
+        raise RefPanic(ERR_DIVISION_BY_ZERO, "attempt to divide by zero")
+    div, rem = divmod(a, b)
+    na, nb = len(a_limbs), len(b_limbs)
+    nd = 0 if nb > na + 1 else na - nb + 1
+    return limbs_of(div, nd), limbs_of(rem, nb)       # set_biguint_target asserts the value fits (:456,473)
 
 
 def gl(v):

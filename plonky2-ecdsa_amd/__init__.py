@@ -33,6 +33,7 @@ LIB_PATH = os.path.join(_HERE, "libp2e_hip.so")
 FIELD_BASE = 0    # plonky2 Secp256K1Base
 FIELD_SCALAR = 1  # plonky2 Secp256K1Scalar
 ERR_LIMB_RANGE, ERR_VALUE_GE_2_256, ERR_INVERSE_OF_ZERO, ERR_CARRY_RANGE, ERR_QUOTIENT_RANGE = 1, 2, 4, 8, 16
+ERR_DIVISION_BY_ZERO = 32
 CTX_HOST_POINTERS, CTX_ASYNC = 1, 2
 VERIFY_COLS = 82615
 GLV_MUL_COLS = 65243
@@ -49,7 +50,7 @@ EXPORTS = (
     "p2e_schedule_describe",
     "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
     "p2e_compact_layout", "p2e_columns_compact", "p2e_ecdsa_verify_witness_compact_batch",
-    "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch", "p2e_compact_to_rows", "p2e_ecdsa_verify_batch",
+    "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch", "p2e_compact_to_rows", "p2e_ecdsa_verify_batch", "p2e_biguint_div_rem_batch",
 )
 
 
@@ -289,6 +290,17 @@ class Context:
         bad = self._check(self._L.p2e_inv_witness_batch(self._h, C.c_int(field), _ptr(x), _ptr(inv), _ptr(div),
                                                         C.c_size_t(n), C.c_size_t(n), _ptr(err)))
         return inv, div, err, bad
+
+    def biguint_div_rem_batch(self, a, b):
+        """BigUintDivRemGenerator (gadgets/biguint.rs:508-518): a (na, n), b (nb, n) limb columns ->
+        (div (max(0, na - nb + 1), n), rem (nb, n), err, flagged)."""
+        na, n = self._shape(a)
+        nb = self._shape(b)[0]
+        nd = 0 if nb > na + 1 else na - nb + 1
+        div, rem, err = self._cols(max(nd, 1), n), self._cols(nb, n), self._vec(n, np.uint8)
+        bad = self._check(self._L.p2e_biguint_div_rem_batch(self._h, _ptr(a), C.c_int(na), _ptr(b), C.c_int(nb), _ptr(div),
+                                                            _ptr(rem), C.c_size_t(n), C.c_size_t(n), _ptr(err)))
+        return div[:nd], rem, err, bad
 
     def glv_decompose_batch(self, k):
         """GLVDecompositionGenerator (gadgets/glv.rs:128-142)."""

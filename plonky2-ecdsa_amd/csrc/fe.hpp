@@ -36,7 +36,7 @@ constexpr u64 P_GL = 0xFFFFFFFF00000001ull;  // Goldilocks
 
 // error bits, mirrored in include/p2e.h
 constexpr uint8_t ERR_LIMB_RANGE = 1, ERR_VALUE_GE_2_256 = 2, ERR_INVERSE_OF_ZERO = 4, ERR_CARRY_RANGE = 8,
-                  ERR_QUOTIENT_RANGE = 16;
+                  ERR_QUOTIENT_RANGE = 16, ERR_DIVISION_BY_ZERO = 32;
 
 // ------------------------------------------------------------------------------------------------
 // moduli: m = 2^256 - C

@@ -172,6 +172,16 @@ __global__ __launch_bounds__(BS) void k_inv(const u64* x, u64* inv, u64* div, si
     }
     count_err(e, counter);
 }
+__global__ __launch_bounds__(BS) void k_div_rem(const u64* a, int na, const u64* b, int nb, u64* div, u64* rem, size_t n, size_t ld,
+                                                uint8_t* err, unsigned long long* counter) {
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    uint8_t e = 0;
+    if (i < n) {
+        e = prim_div_rem(a, na, b, nb, div, rem, ld, i);
+        err[i] = e;
+    }
+    count_err(e, counter);
+}
 __global__ __launch_bounds__(BS) void k_glv(const u64* k, u64* k1, u64* k2, u64* n1, u64* n2, size_t n, size_t ld,
                                             uint8_t* err, unsigned long long* counter) {
     size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
@@ -793,6 +803,23 @@ extern "C" long p2e_inv_witness_batch(p2e_ctx* c, int field, const uint64_t* x, 
         hipLaunchKernelGGL(k_inv<ModP>, grid1(n), dim3(BS), 0, c->stream, x, inv, div, n, ld, err, c->d_counter);
     else
         hipLaunchKernelGGL(k_inv<ModN>, grid1(n), dim3(BS), 0, c->stream, x, inv, div, n, ld, err, c->d_counter);
+    return S.done(finish_call(c));
+}
+extern "C" long p2e_biguint_div_rem_batch(p2e_ctx* c, const uint64_t* a, int na, const uint64_t* b, int nb, uint64_t* div,
+                                          uint64_t* rem, size_t n, size_t ld, uint8_t* err) {
+    const int nd = nb > na + 1 ? 0 : na - nb + 1;
+    if (bad_common(c, n, ld) || na < 1 || na > 18 || nb < 1 || nb > 9 || !a || !b || (nd > 0 && !div) || !rem || !err)
+        return P2E_E_INVALID;
+    if (n == 0) return 0;
+    Staged S(c);
+    a = S.in(a, (size_t)na * ld * 8);
+    b = S.in(b, (size_t)nb * ld * 8);
+    if (nd > 0) div = S.out(div, (size_t)nd * ld * 8);
+    rem = S.out(rem, (size_t)nb * ld * 8);
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    hipLaunchKernelGGL(k_div_rem, grid1(n), dim3(BS), 0, c->stream, a, na, b, nb, div, rem, n, ld, err, c->d_counter);
     return S.done(finish_call(c));
 }
 extern "C" long p2e_glv_decompose_batch(p2e_ctx* c, const uint64_t* k, uint64_t* k1, uint64_t* k2, uint64_t* n1,

@@ -237,6 +237,114 @@ P2E_HD uint8_t prim_glv(const u64* k, u64* k1, u64* k2, u64* n1, u64* n2, size_t
     return err;
 }
 
+// gadgets/biguint.rs:508-518 BigUintDivRemGenerator (the 8th and last generator of the crate; used by rem_biguint /
+// reduce, gadgets/nonnative.rs:539-548): a (na <= 18 limbs) = div * b + rem, b (nb <= 9 limbs).  Limb counts of the
+// outputs as div_rem_biguint allocates them (:391-397): nd = na - nb + 1 (0 if nb > na + 1), nb.  Restoring binary
+// division, one quotient bit per step, everything in registers (static indices only); not a hot path.
+// Flags: a limb >= 2^29 (deviation: the reference would sum arbitrary field elements), b == 0 (BigUint::div_rem
+// panics), and a quotient that set_biguint_target rejects -- INCLUDING the reference's quirk that convert_base hands it
+// floor(32 D / 29) limbs for a D-digit value, zero limbs included, so e.g. a 290-bit quotient "does not fit" 10 limbs.
+P2E_HD uint8_t prim_div_rem(const u64* a, int na, const u64* b, int nb, u64* div, u64* rem, size_t ld, size_t i) {
+    uint8_t err = 0;
+    u32 aw[17], bw[9];
+    P2E_UNROLL
+    for (int k = 0; k < 17; k++) aw[k] = 0;
+    P2E_UNROLL
+    for (int k = 0; k < 9; k++) bw[k] = 0;
+    P2E_UNROLL
+    for (int k = 0; k < 18; k++) {
+        if (k < na) {
+            const u64 l = a[(size_t)k * ld + i];
+            if (l >> BITS) err |= ERR_LIMB_RANGE;
+            const int bit = BITS * k, wi = bit >> 5, sh = bit & 31;
+            const u64 v = (l & MASK29) << sh;
+            aw[wi] |= (u32)v;
+            if (wi + 1 < 17) aw[wi + 1] |= (u32)(v >> 32);
+        }
+    }
+    u32 any_b = 0;
+    P2E_UNROLL
+    for (int k = 0; k < 9; k++) {
+        if (k < nb) {
+            const u64 l = b[(size_t)k * ld + i];
+            if (l >> BITS) err |= ERR_LIMB_RANGE;
+            const int bit = BITS * k, wi = bit >> 5, sh = bit & 31;
+            const u64 v = (l & MASK29) << sh;
+            bw[wi] |= (u32)v;
+            if (wi + 1 < 9) bw[wi + 1] |= (u32)(v >> 32);
+            any_b |= (u32)(l & MASK29);
+        }
+    }
+    if (!any_b) err |= ERR_DIVISION_BY_ZERO;
+    u32 r[9], q[17];
+    P2E_UNROLL
+    for (int k = 0; k < 9; k++) r[k] = 0;
+    P2E_UNROLL
+    for (int w = 16; w >= 0; w--) {
+        u32 word = aw[w], qw = 0;
+        for (int j = 0; j < 32; j++) {
+            u32 carry = word >> 31;
+            word <<= 1;
+            P2E_UNROLL
+            for (int k = 0; k < 9; k++) {   // r = (r << 1) | next bit of a      (r < b < 2^261: no overflow)
+                const u32 nk = (r[k] << 1) | carry;
+                carry = r[k] >> 31;
+                r[k] = nk;
+            }
+            u32 t[9], borrow = 0;
+            P2E_UNROLL
+            for (int k = 0; k < 9; k++) {   // t = r - b
+                const u64 d = (u64)r[k] - bw[k] - borrow;
+                t[k] = (u32)d;
+                borrow = (u32)(d >> 63);
+            }
+            const bool ge = borrow == 0;
+            P2E_UNROLL
+            for (int k = 0; k < 9; k++) r[k] = ge ? t[k] : r[k];
+            qw = (qw << 1) | (ge ? 1u : 0u);
+        }
+        q[w] = qw;
+    }
+    const int nd = nb > na + 1 ? 0 : na - nb + 1;
+    // limbs set_biguint_target would be handed for the quotient (see the header comment)
+    int digits = 0;
+    u32 top = 0;
+    P2E_UNROLL
+    for (int k = 0; k < 17; k++)
+        if (q[k]) {
+            digits = k + 1;
+            top = q[k];
+        }
+    int bitlen = 0;
+    if (digits) {
+        int lz = 0;
+        while (!(top >> 31)) {
+            top <<= 1;
+            lz++;
+        }
+        bitlen = 32 * digits - lz;
+    }
+    const int l0 = (32 * digits) / BITS;
+    if (!err && l0 + (bitlen > BITS * l0 ? 1 : 0) > nd) err |= ERR_LIMB_RANGE;   // (the quotient by zero is garbage)
+    P2E_UNROLL
+    for (int k = 0; k < 18; k++) {
+        if (k < nd) {
+            const int bit = BITS * k, wi = bit >> 5, sh = bit & 31;
+            const u64 lo = q[wi], hi = wi + 1 < 17 ? q[wi + 1] : 0;
+            div[(size_t)k * ld + i] = err ? 0 : (((lo | (hi << 32)) >> sh) & MASK29);
+        }
+    }
+    P2E_UNROLL
+    for (int k = 0; k < 9; k++) {
+        if (k < nb) {
+            const int bit = BITS * k, wi = bit >> 5, sh = bit & 31;
+            const u64 lo = r[wi], hi = wi + 1 < 9 ? r[wi + 1] : 0;
+            rem[(size_t)k * ld + i] = err ? 0 : (((lo | (hi << 32)) >> sh) & MASK29);
+        }
+    }
+    return err;
+}
+
 // gadgets/biguint.rs:27-51,454-463: 256-bit packed LE -> nine 29-bit limb columns
 P2E_HD void prim_split(const uint8_t* packed, u64* limbs, size_t ld, size_t i) {
     U256 v = *reinterpret_cast<const U256*>(packed + 32 * i);

@@ -26,6 +26,7 @@ class OracleBackend:
     pack = staticmethod(oracle_c.limb_pack)
     verify = staticmethod(lambda *a: oracle_c.verify_witness(*a))
     glv_mul = staticmethod(lambda *a: oracle_c.glv_mul_witness(*a))
+    div_rem = staticmethod(lambda a, b: oracle_c.div_rem(a, b))
 
     @staticmethod
     def aux(program, inputs):
@@ -50,7 +51,7 @@ class EmuBackend:
         self.L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libp2e_emu.so"))
         for f in ("emu_verify", "emu_glv_mul", "emu_mul", "emu_checksum", "emu_add", "emu_sub", "emu_add_many",
                   "emu_inv", "emu_glv", "emu_split", "emu_pack", "emu_aux", "emu_aux_num_cols", "emu_verify_compact",
-                  "emu_glv_mul_compact", "emu_aux_compact", "emu_verify_only"):
+                  "emu_glv_mul_compact", "emu_aux_compact", "emu_verify_only", "emu_div_rem"):
             getattr(self.L, f).restype = C.c_long
 
     def mul(self, field, x, y):
@@ -59,6 +60,14 @@ class EmuBackend:
         r, q, cs, b, err = _z(9, n), _z(9, n), _z(17, n), _z(16, n), np.zeros(n, np.uint8)
         self.L.emu_mul(C.c_int(field), _p(x), _p(y), _p(r), _p(q), _p(cs), _p(b), C.c_size_t(n), C.c_size_t(n), _p(err))
         return r, q, cs, b, err
+
+    def div_rem(self, a, b):
+        a, b = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b, np.uint64)
+        na, nb, n = a.shape[0], b.shape[0], a.shape[1]
+        nd = 0 if nb > na + 1 else na - nb + 1
+        div, rem, err = _z(max(nd, 1), n), _z(nb, n), np.zeros(n, np.uint8)
+        self.L.emu_div_rem(_p(a), C.c_int(na), _p(b), C.c_int(nb), _p(div), _p(rem), C.c_size_t(n), C.c_size_t(n), _p(err))
+        return div[:nd], rem, err
 
     def checksum(self, a):
         a = np.ascontiguousarray(a, np.uint64)
@@ -217,6 +226,9 @@ class GpuBackend:
 
     def glv(self, k):
         return self.ctx.glv_decompose_batch(self._c(k))[:5]
+
+    def div_rem(self, a, b):
+        return self.ctx.biguint_div_rem_batch(self._c(a), self._c(b))[:3]
 
     def split(self, packed):
         return self.ctx.limb_split(self._c(packed, np.uint8))

@@ -319,6 +319,9 @@ long emu_add_many(int field, const u64* s, int k, u64* out, u64* ov, size_t n, s
 long emu_inv(int field, const u64* x, u64* inv, u64* div, size_t n, size_t ld, uint8_t* err) {
     LOOP(field ? prim_inv<ModN>(x, inv, div, ld, i) : prim_inv<ModP>(x, inv, div, ld, i))
 }
+long emu_div_rem(const u64* a, int na, const u64* b, int nb, u64* div, u64* rem, size_t n, size_t ld, uint8_t* err) {
+    LOOP(prim_div_rem(a, na, b, nb, div, rem, ld, i))
+}
 long emu_glv(const u64* k, u64* k1, u64* k2, u64* n1, u64* n2, size_t n, size_t ld, uint8_t* err) {
     LOOP(prim_glv(k, k1, k2, n1, n2, ld, i))
 }

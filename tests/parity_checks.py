@@ -56,6 +56,21 @@ def check_inv(be):
         _check(f"inv/{field}", (inv, div), want, np.asarray(err), want_err)
 
 
+def check_div_rem(be):
+    """BigUintDivRemGenerator KATs, one batch per (na, nb) shape."""
+    shapes = sorted({(k["na"], k["nb"]) for k in KATS["div_rem"]})
+    for na, nb in shapes:
+        ks = [k for k in KATS["div_rem"] if (k["na"], k["nb"]) == (na, nb)]
+        nd = 0 if nb > na + 1 else na - nb + 1
+        a = np.array([k["a"] for k in ks], dtype=np.uint64).T.copy()
+        b = np.array([k["b"] for k in ks], dtype=np.uint64).T.copy()
+        want_err = np.array([k["err"] for k in ks], dtype=np.uint8)
+        want_div = np.array([k["div"] if k["div"] is not None else [0] * nd for k in ks], dtype=np.uint64).reshape(len(ks), nd).T
+        want_rem = np.array([k["rem"] if k["rem"] is not None else [0] * nb for k in ks], dtype=np.uint64).T
+        div, rem, err = be.div_rem(a, b)
+        _check(f"div_rem/{na}x{nb}", (div, rem), (want_div, want_rem), np.asarray(err), want_err)
+
+
 def check_add_many(be):
     for field in (0, 1):
         for kk in (2, 4, 8):
@@ -154,7 +169,8 @@ def golden_schedule(name):
         return [tuple(x) for x in json.load(f)]
 
 
-ALL_PRIM_CHECKS = (check_add_sub, check_mul, check_inv, check_add_many, check_glv, check_checksum, check_split_pack)
+ALL_PRIM_CHECKS = (check_add_sub, check_mul, check_inv, check_add_many, check_glv, check_checksum, check_split_pack,
+                   check_div_rem)
 
 
 def structured_values(seed, count, bound_bits=256):

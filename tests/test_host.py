@@ -148,6 +148,32 @@ def test_plain_c_client_builds_against_the_header_and_fails_loudly_without_a_gpu
     assert r.returncode == 2 and "no CPU fallback" in r.stderr
 
 
+def test_div_rem_bodies_random_shapes():
+    """BigUintDivRemGenerator body (restoring division in registers) against the C oracle (Knuth D) on random operands of
+    every supported shape, quotients pushed into the zone where the reference's set_biguint_target quirk bites."""
+    import random
+    emu, ora = EmuBackend(), OracleBackend()
+    rnd = random.Random(4242)
+    split = lambda v, k: [(v >> (29 * i)) & ((1 << 29) - 1) for i in range(k)]
+    flagged = 0
+    for na, nb in ((18, 9), (9, 9), (10, 9), (17, 8), (18, 1), (5, 9), (9, 5), (3, 3), (1, 1), (12, 7), (2, 9)):
+        nd = 0 if nb > na + 1 else na - nb + 1
+        A, Bv = [], []
+        for t in range(120):
+            a, b = rnd.getrandbits(rnd.randint(0, 29 * na)), rnd.getrandbits(rnd.randint(1, 29 * nb))
+            if t % 3 == 0 and b and nd:
+                a = min((1 << (29 * na)) - 1, b * rnd.getrandbits(max(1, 29 * nd - rnd.randint(0, 4))) + rnd.randrange(b))
+            if t == 1:
+                b = 0
+            A.append(split(a, na)), Bv.append(split(b, nb))
+        a, b = np.array(A, dtype=np.uint64).T.copy(), np.array(Bv, dtype=np.uint64).T.copy()
+        want, got = ora.div_rem(a, b), emu.div_rem(a, b)
+        assert np.array_equal(got[2], want[2]), (na, nb)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (na, nb)
+        flagged += int((want[2] != 0).sum())
+    assert flagged > 30      # division by zero and the quirk zone are really exercised
+
+
 def test_synth_signatures_restates_sign_message():
     arrs = p2e.synth_signatures(seed=9, n=4, first=2)
     for i in range(4):
