@@ -649,8 +649,8 @@ P2E_HD bool fe_inv_bingcd(const U256& y, U256& result) {
             xb = tb;
             f0 = odd ? tf0 - tf1 : tf0;
             g0 = odd ? tg0 - tg1 : tg0;
-            f1 = tf1 << 1;
-            g1 = tg1 << 1;
+            f1 = tf1 * 2;   // (not << 1: shifting a negative value is undefined before C++20; |f|, |g| <= 2^31)
+            g1 = tg1 * 2;
         }
         u32 na_[8], nb_[8];
         const bool sf0 = f0 < 0, sg0 = g0 < 0, sf1 = f1 < 0, sg1 = g1 < 0;
