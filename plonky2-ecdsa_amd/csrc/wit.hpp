@@ -162,7 +162,13 @@ struct PStream {
     }
     // Output columns are write-once / never re-read by the pipeline: non-temporal stores keep them from
     // displacing the scratch arrays that phases B and C are about to read (-1.6 % on the whole step).
-    P2E_HD void store_single(int c, T v) { __builtin_nontemporal_store(v, slot2(c) + delta); }
+    // The running pointer went through an asm barrier, which hides from the compiler that it points into global
+    // memory: without the explicit address-space casts below every column store is a FLAT store (counted in lgkmcnt
+    // as well, so each scalar-load wait also waits for the stores).
+    P2E_HD void store_single(int c, T v) {
+        typedef T __attribute__((address_space(1))) * gptr;
+        __builtin_nontemporal_store(v, (gptr)(slot2(c) + delta));
+    }
     P2E_HD void store_pair(int c, T a, T b) {   // a: my value of column c, b: of column c + 1
         if (sizeof(T) == 8) {
             u32 ax = (u32)a, ay = (u32)((u64)a >> 32), bx = (u32)b, by = (u32)((u64)b >> 32);
@@ -170,12 +176,14 @@ struct PStream {
             auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
             typedef unsigned int v4u __attribute__((ext_vector_type(4)));
             v4u ov = {r0[0], r1[0], r0[1], r1[1]};
-            __builtin_nontemporal_store(ov, reinterpret_cast<v4u*>(slot2(c)));
+            typedef v4u __attribute__((address_space(1))) * gptr;
+            __builtin_nontemporal_store(ov, (gptr)slot2(c));
         } else {
             auto r0 = __builtin_amdgcn_permlane32_swap((u32)a, (u32)b, false, false);
             typedef unsigned int v2u __attribute__((ext_vector_type(2)));
             v2u ov = {r0[0], r0[1]};
-            __builtin_nontemporal_store(ov, reinterpret_cast<v2u*>(slot2(c)));
+            typedef v2u __attribute__((address_space(1))) * gptr;
+            __builtin_nontemporal_store(ov, (gptr)slot2(c));
         }
     }
     P2E_HD void put(T v) {
