@@ -332,6 +332,29 @@ def test_verdict_only_matches_full_fill(ora):
     assert verr[17] & R.ERR_INVERSE_OF_ZERO and 0 < int(vvalid.sum()) < n
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 65, 257])
+def test_tiny_and_odd_batches_every_output(n):
+    """Batch sizes below / around a wavefront and a workgroup: u64 matrix (device and staged host pointers), compact
+    container, built-in-generator columns and the verdict-only call against the oracle."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    sigs = p2e.synth_signatures(seed=1000 + n, n=n)
+    want, waux, _werr, _wflags = oracle_c.verify_witness_aux(*sigs)
+    ctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    cols, _err, valid, bad = ctx.ecdsa_verify_witness_batch(*dev)
+    aux, _aerr, abad = ctx.aux_witness_batch(0, dev[4], cols, n=n, ld=cols.stride(0))
+    nar, wid, _cerr, cvalid, cbad = ctx.ecdsa_verify_witness_compact_batch(*dev)
+    _verr, vvalid, vbad = ctx.ecdsa_verify_batch(*dev)
+    torch.cuda.synchronize()
+    assert bad + abad + cbad + vbad == 0 and int(valid.sum()) == n == int(vvalid.sum()) == int(cvalid.sum())
+    assert np.array_equal(cols.cpu().numpy().view(np.uint64), want)
+    assert np.array_equal(aux.cpu().numpy().view(np.uint64), waux)
+    assert np.array_equal(p2e.compact_expand(0, nar.cpu().numpy().view(np.uint32), wid.cpu().numpy()), want)
+    hcols = p2e.Context(device=0, host_pointers=True).ecdsa_verify_witness_batch(*sigs)[0]
+    assert np.array_equal(np.asarray(hcols).view(np.uint64), want)
+
+
 def test_plain_c_client(tmp_path):
     """examples/fill_batch.c: a C11 program on the C ABI alone (no torch, no Python in the process)."""
     import subprocess
