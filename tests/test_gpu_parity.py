@@ -429,3 +429,40 @@ def test_full_size_batch_properties():
     sel_rows = [r for kind, f, _n, _l in items if kind in ("fixed_base_window", "msm_digit")
                 for r in range(f + (2 if kind == "fixed_base_window" else 1), f + (2 if kind == "fixed_base_window" else 1) + 18)]
     assert int((aux_full[torch.tensor(sel_rows[::5], device="cuda")] >> 29).ne(0).sum()) == 0
+
+
+def test_gpu_output_passes_the_constraint_replay():
+    """No oracle VALUES involved: the HIP kernels' columns (and built-in-generator columns) of fresh signatures go
+    straight into the reference's constraint equations (oracle/check_circuit.py: every add / sub / add_many / inv
+    relation with its operands, both mul gates, the range checks, GLV, the three connects), and a corrupted GPU
+    column is rejected."""
+    import torch
+    import check_circuit as CC
+    import plonky2_ecdsa_amd as p2e
+    n = 300
+    sigs = p2e.synth_signatures(seed=2024, n=n)
+    ctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    cols, err, valid, bad = ctx.ecdsa_verify_witness_batch(*dev)
+    aux, _aerr, abad = ctx.aux_witness_batch(0, dev[4], cols, n=n, ld=cols.stride(0))
+    torch.cuda.synchronize()
+    assert bad == 0 and abad == 0 and int(valid.sum()) == n
+    host, haux = cols.cpu().numpy().view(np.uint64), aux.cpu().numpy().view(np.uint64)
+    for i in (0, 63, 64, 255, 299):                       # both half-waves, a workgroup boundary, the ragged tail
+        ins = CC.unpack_inputs(sigs, i)
+        c = CC.check_verify(host[:, i], *ins, aux=haux[:, i])
+        assert len(c.gens) == 3555
+    bad_cols = host[:, 7].copy()
+    bad_cols[41234] ^= np.uint64(1)
+    with pytest.raises(CC.ConstraintViolation):
+        CC.check_verify(bad_cols, *CC.unpack_inputs(sigs, 7))
+    # glv_mul program
+    rng = R.SplitMix64(2025)
+    ks = [rng.below(R.N) for _ in range(n)]
+    gcols, gerr, _gvalid, gbad = ctx.glv_mul_witness_batch(dev[3], dev[4], torch.from_numpy(oracle_c.pack256(ks)).cuda())
+    torch.cuda.synchronize()
+    assert gbad == 0
+    ghost = gcols.cpu().numpy().view(np.uint64)
+    for i in (1, 298):
+        px, py = CC.unpack_inputs(sigs[3:5], i)
+        CC.check_glv_mul(ghost[:, i], px, py, ks[i])

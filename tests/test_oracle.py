@@ -100,14 +100,13 @@ def test_python_ref_vs_c_oracle_random_signatures():
         assert ok and np.array_equal(np.array(ref, dtype=np.uint64), cols[:, i])
 
 
-def test_verify_constraints_hold_on_every_mul_row():
-    """Re-evaluate MulNonnativeGate / CheckSumGate constraints (gates/mul_nonnative.rs:101-130,:411-427) on
-    every mul of a golden witness, and the add/sub/inv equations (gadgets/nonnative.rs:262-267,376-380,518-524)
-    on every such op: this is what a plonky2 prove+verify of the reference's tests would enforce."""
+def test_self_contained_ranges_on_every_generator_of_a_golden_witness():
+    """Cheap, operand-free sanity on every generator's own columns (ranges, the CheckSumGate carry chain).  The
+    reference's constraint equations WITH their operands (add/sub/inv/add_many relations, MulNonnativeGate, GLV,
+    the three connects) are replayed by oracle/check_circuit.py: tests/test_check_circuit.py."""
     cols, inputs, valid = pc.load_verify_golden()
     ops = pc.golden_schedule("verify")
     col = cols[:, 0]
-    # replay the walker to know operands; here we only check self-contained equations
     for kind, field, c0, nc, label in ops:
         m = R.MODULI[field]
         seg = [int(v) for v in col[c0:c0 + nc]]
