@@ -11,6 +11,11 @@ inputs already resident in HBM, output columns written to HBM.  One process per 
 sharded by contiguous signature ranges with no data-path collective ("scaling": "weak": per-GPU work is
 fixed as N grows).  Rank 0 prints ONE JSON line.
 
+  --scaling strong   the metric's literal shape: ONE global batch of 2^16 split over the N ranks (8 192
+                     signatures per GPU at N = 8).  value = the whole batch / the max-over-ranks time of the fill;
+                     the RCCL all-gather that assembles the full column matrix on every rank (north star) is timed
+                     separately and reported beside it ("allgather", and "value_with_allgather").
+
 Extra objects on the line:
   roofline     the dominant kernel, k_expand_runs (the MSM double/double/conditional-add loop: 59 495 of the
                82 615 columns, one launch per schedule segment of the loop).  achieved = algorithmic bytes
@@ -19,9 +24,14 @@ Extra objects on the line:
                rocprofv3 PMC summary committed under profiles/ (null if absent).
   roofline_k_expand   the same figures for k_expand (window table, fixed-base chain, trailing adds: 22 572
                columns, one curve op per workgroup row).
+  roofline_limb_split   the 29-bit limb-split kernel (k_split, p2e_limb_split) on 2^26 packed 256-bit values:
+               104 algorithmic bytes per element (32 in + 72 out), torch events on the stream it runs on.
   cpu_baseline oracle/libp2e_oracle.so (C restatement of the reference's CPU algorithm: affine ops, one
                Fermat inversion per inverse, OpenMP over signatures) timed on a bounded sample on the
                host cores of this box.  kind "port": the Rust reference cannot be built offline.
+  cpu_baseline_optimised   the same C code with Montgomery batch inversion across lock-step groups of 256
+               signatures (BASELINE.md section 2 variant b): the baseline a careful CPU implementation would set.
+  checked_vs_oracle   signatures of the LAST timed output buffer compared column by column with the C oracle.
 """
 import argparse
 import json
@@ -71,9 +81,26 @@ def cpu_baseline(p2e, seed):
     cols, err, flags = oracle_c.verify_witness(*sigs, nthreads=cores)
     dt = time.time() - t
     assert not err.any() and flags.all()
-    return {"value": round(n / dt, 2), "unit": "fills/s", "cores": cores, "kind": "port",
+    base = {"value": round(n / dt, 2), "unit": "fills/s", "cores": cores, "kind": "port",
             "sample": f"{n} signatures of the same synthetic batch, all {cores} host threads (OpenMP), "
                       f"{dt:.1f} s; oracle/p2e_oracle.c (schoolbook mul + Knuth D, one Fermat ladder per inverse)"}
+    # variant b: batch inversion across lock-step groups of 256 signatures, everything else unchanged
+    group = 256
+    t = time.time()
+    oracle_c.verify_witness_lockstep(*[a[:group * cores] for a in p2e.synth_signatures(seed=seed, n=group * cores)],
+                                     nthreads=cores, group=group)
+    rate = group * cores / max(time.time() - t, 1e-3)
+    n2 = max(1, int(min(rate * 10.0, 40000) // (group * cores))) * group * cores          # whole groups per thread, ~10 s
+    sigs2 = p2e.synth_signatures(seed=seed, n=n2)
+    t = time.time()
+    cols2, err2, flags2 = oracle_c.verify_witness_lockstep(*sigs2, nthreads=cores, group=group)
+    dt2 = time.time() - t
+    assert not err2.any() and flags2.all() and (cols2[:, :min(n, n2)] == cols[:, :min(n, n2)]).all()
+    opt = {"value": round(n2 / dt2, 2), "unit": "fills/s", "cores": cores, "kind": "port",
+           "sample": f"{n2} signatures, {cores} host threads, {dt2:.1f} s; same C code with Montgomery batch inversion "
+                     f"across lock-step groups of {group} signatures (one Fermat ladder per group and inverse op); "
+                     "columns identical to the faithful variant"}
+    return base, opt
 
 
 def pmc_traffic():
@@ -95,7 +122,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-log2", type=int, default=16, help="signatures per GPU = 2^k (metric: 16)")
+    ap.add_argument("--batch-log2", type=int, default=16,
+                    help="weak: signatures per GPU = 2^k; strong: signatures of the global batch = 2^k (metric: 16)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--allgather-reps", type=int, default=2, help="strong, N>1: timed repetitions of the full-matrix all-gather")
+    ap.add_argument("--no-limb-split", action="store_true", help="skip the limb-split roofline leg")
+    ap.add_argument("--check", type=int, default=16, help="signatures of the last output buffer compared with the oracle")
     ap.add_argument("--allgather-cols", type=int, default=0,
                     help="N>1 only: after the timed region, all-gather this many columns over RCCL and report GB/s")
     ap.add_argument("--ld-pad", type=int, default=16, help="column stride = batch + this many elements")
@@ -133,11 +165,14 @@ def main():
     dev = f"cuda:{dev_index}"
     local_rank = dev_index
 
-    n = 1 << args.batch_log2
-    total = n * world
     from plonky2_ecdsa_amd.dist import shard_bounds
+    if args.scaling == "strong":
+        total = 1 << args.batch_log2                                       # ONE global batch, split over the ranks
+    else:
+        total = (1 << args.batch_log2) * world                             # 2^k signatures per GPU
     start, end = shard_bounds(total, rank, world)
-    sigs = p2e.synth_signatures(seed=4, n=end - start, first=start)       # seed 0x4: SURVEY.md 8(d) cfg-4
+    n = end - start
+    sigs = p2e.synth_signatures(seed=4, n=n, first=start)                  # seed 0x4: SURVEY.md 8(d) cfg-4
     depth = max(1, args.pipeline_depth)
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(depth - 1)]
     ctxs = [p2e.Context(device=local_rank, stream=st.cuda_stream, asynchronous=depth > 1) for st in streams]
@@ -198,12 +233,15 @@ def main():
             st["cols"], st["launches"] = ph[k + "_cols"], int(ph[k + "_launches"])
         for k in ("scalar", "expand", "runs", "total"):
             phase_acc[k] = phase_acc.get(k, 0.0) + ph[k] * weight
+    step_s = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
         if depth > 1:
             continue
+        step_s.append(time.perf_counter() - ts)      # calls are synchronous at depth 1: the step's own wall time
         note(ctx.last_phase_ms())
     if depth > 1:
         drain()
@@ -218,7 +256,31 @@ def main():
         elapsed = float(t.item())
 
     gather = None
-    if world > 1 and args.allgather_cols > 0 and not args.compact:
+    if world > 1 and args.scaling == "strong" and not args.compact:
+        # north star: "RCCL all-gather over xGMI to assemble the Goldilocks witness columns" -- the whole matrix of the
+        # global batch on every rank: ONE collective straight from the padded output buffer (no copy, dist.py)
+        from plonky2_ecdsa_amd.dist import all_gather_columns, gather_buffer
+        src = cols_bufs[0][:, :n] if backend == "nccl" else cols_bufs[0][:, :n].cpu()
+        gbuf = gather_buffer(src, world)
+        g = all_gather_columns(src, total, n_local=n, out=gbuf)            # warm-up: RCCL channels
+        times = []
+        for _ in range(max(1, args.allgather_reps)):
+            barrier()
+            tg = time.perf_counter()
+            g = all_gather_columns(src, total, n_local=n, out=gbuf)
+            barrier()
+            times.append(time.perf_counter() - tg)
+        tg = sorted(times)[len(times) // 2]
+        if world > 1:
+            t = torch.tensor([tg], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tg = float(t.item())
+        recv = (world - 1) * p2e.VERIFY_COLS * n * 8
+        gather = {"what": "full column matrix of the global batch assembled on every rank (all_gather_into_tensor, "
+                          f"{backend})", "ms": round(tg * 1e3, 3), "bytes_received_per_rank": recv,
+                  "GBps_received_per_rank": round(recv / tg / 1e9, 1), "reps": len(times)}
+        del g, gbuf
+    elif world > 1 and args.allgather_cols > 0 and not args.compact:
         from plonky2_ecdsa_amd.dist import all_gather_columns
         k = min(args.allgather_cols, p2e.VERIFY_COLS)
         barrier()
@@ -230,11 +292,51 @@ def main():
                   "GBps_per_rank": round(g.numel() * 8 / tg / 1e9, 1)}
         del g
 
+    checked = None
+    if rank == 0 and args.check > 0 and not args.compact:
+        # bit-exactness of THIS run: sampled signatures of the last output buffer against the C oracle, every column
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_c
+        last = cols_bufs[(issued[0] - 1) % depth] if issued[0] else cols_bufs[0]
+        sample = np.unique(np.linspace(0, n - 1, min(args.check, n)).astype(np.int64))
+        want, werr, wflags = oracle_c.verify_witness(*[a[sample] for a in sigs])
+        got = last[:, torch.from_numpy(sample).to(dev)].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, want) and not werr.any() and wflags.all(), "GPU columns differ from the oracle"
+        checked = int(len(sample))
+
+    limb_split = None
+    if rank == 0 and not args.no_limb_split:
+        # the 29-bit limb-split kernel of the north star (>= 40 % of HBM peak asked): 2^26 packed values -> 9 limb columns
+        m = 1 << 26
+        packed = torch.randint(0, 256, (m, 32), dtype=torch.uint8, device=dev)
+        limbs = torch.empty((9, m), dtype=torch.int64, device=dev)
+        for _ in range(2):
+            ctx.limb_split(packed, out=limbs)
+        reps = 10
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for k in range(reps):                          # the context runs on torch's current stream: the events see it
+            ctx.limb_split(packed, out=limbs)
+            ev[k + 1].record()
+        torch.cuda.synchronize()
+        ms = sorted(ev[k].elapsed_time(ev[k + 1]) for k in range(reps))
+        med = ms[len(ms) // 2]
+        # one spot check of the split itself
+        v = int.from_bytes(bytes(packed[12345].cpu().numpy()), "little")
+        assert [int(x) for x in limbs[:, 12345].cpu()] == [(v >> (29 * k)) & ((1 << 29) - 1) for k in range(9)]
+        ach = 104 * m / (med / 1e3) / 1e9
+        limb_split = {"kernel": "k_split", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": 104 * m,
+                      "avg_launch_ms": round(med, 4), "elements": m, "traffic": None,
+                      "note": "median of 10 launches incl. the call's own stream sync; 104 B/element (32 packed in + 9 x 8 out)"}
+        del packed, limbs
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed
         # the committed PMC summary was collected on the metric's batch (2^16 per GPU): no traffic figure otherwise
-        pmc = (pmc_traffic() or {}) if args.batch_log2 == 16 else {}
+        pmc = (pmc_traffic() or {}) if (args.batch_log2 == 16 and args.scaling == "weak") else {}
 
         def roofline(kernel, st):
             # `launches` launches per step (one per schedule segment); per launch:
@@ -258,11 +360,13 @@ def main():
         line = {
             "metric": "secp256k1 ECDSA witness fills/sec at batch=2^16, 1/2/4/8 MI355X; bit-exact",
             "value": round(value, 1), "unit": "fills/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"batch 2^{args.batch_log2} ECDSA verifies per GPU (BASELINE configs[3] workload on "
-                                   "one GPU; random valid signatures, seed 4), all 82615 hot-path generator columns, "
-                                   "column-major u64 in HBM",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": (f"ONE global batch of 2^{args.batch_log2} ECDSA verifies split over the ranks "
+                                    "(BASELINE configs[3], the metric's literal shape)" if args.scaling == "strong" else
+                                    f"batch 2^{args.batch_log2} ECDSA verifies per GPU (BASELINE configs[3] workload on one GPU)")
+                                   + "; random valid signatures, seed 4; all 82615 hot-path generator columns, "
+                                   "column-major u64 (Goldilocks) in HBM; arithmetic in 8 x u32 limbs",
                        "container": "compact (u32 narrow + u64 wide matrices), NOT the headline format" if args.compact
                                     else "u64 column matrix",
                        "batch_per_gpu": n, "global_batch": total, "cols_per_fill": p2e.VERIFY_COLS, "ld": ld,
@@ -277,10 +381,20 @@ def main():
         }
         if runs_line:
             line["roofline_k_expand"] = expand_line
+        if step_s:
+            med = sorted(step_s)[len(step_s) // 2]
+            line["median_step_ms"] = round(med * 1e3, 4)            # median of the timed steps
+            line["value_at_median_step"] = round(n / med, 1) if world == 1 else None
+        if limb_split:
+            line["roofline_limb_split"] = limb_split
+        if checked is not None:
+            line["checked_vs_oracle"] = checked
         if gather:
             line["allgather"] = gather
+            if args.scaling == "strong":
+                line["value_with_allgather"] = round(total / (elapsed / args.steps + gather["ms"] / 1e3), 1)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(p2e, seed=4)
+            line["cpu_baseline"], line["cpu_baseline_optimised"] = cpu_baseline(p2e, seed=4)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

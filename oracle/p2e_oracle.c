@@ -13,6 +13,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <ucontext.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -342,6 +343,14 @@ static void gen_add_many(const u64 (*summands)[NL], const int *nls, int k, const
         *ov = 0;
     }
 }
+/* Optimised-CPU baseline variant (variant b): G signatures are walked in lock step, one
+ * coroutine each, and every NonNativeInverseGenerator's FF::inverse() of the group is answered by ONE Fermat ladder
+ * plus 3 (G - 1) multiplications (Montgomery's trick across signatures at the same schedule step).  Everything else
+ * is the faithful-cost algorithm above.  Non-NULL only inside p2e_oracle_verify_witness_lockstep. */
+struct lockstep;
+static __thread struct lockstep *LS = NULL;
+static void ls_invmod(w32 *r, const w32 *a, const w32 *m);
+
 /* gadgets/nonnative.rs:857-872; outputs have k = nl limbs */
 static void gen_inv(const u64 *x, int nl, const w32 *m, u64 *inv, u64 *div, uint8_t *err) {
     w32 xv[8], iv[8], prod[16], q[9], r[8];
@@ -352,7 +361,10 @@ static void gen_inv(const u64 *x, int nl, const w32 *m, u64 *inv, u64 *div, uint
         *err |= P2E_O_ERR_INVERSE_OF_ZERO;
         return;
     }
-    fe_invmod(iv, xv, m);
+    if (LS)
+        ls_invmod(iv, xv, m); /* optimised-CPU variant: batched with the other signatures of the lock-step group */
+    else
+        fe_invmod(iv, xv, m);
     bn_mul(xv, 8, iv, 8, prod);
     bn_divrem(prod, 16, m, 8, q, r);
     if (words_to_limbs(iv, 8, inv, nl) | words_to_limbs(q, 9, div, nl)) *err |= P2E_O_ERR_LIMB_RANGE;
@@ -870,6 +882,87 @@ static void walk_verify(walker *w, const uint8_t *msg32, const uint8_t *r32, con
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* lock-step groups: batch inversion across signatures (optimised-CPU baseline only)            */
+/* ------------------------------------------------------------------------------------------ */
+#define LS_MAX 256
+#define LS_STACK (512 * 1024)
+typedef struct lockstep {
+    ucontext_t main, co[LS_MAX];
+    char *stack;
+    w32 req[LS_MAX][8], res[LS_MAX][8];
+    const w32 *mod[LS_MAX];
+    int pending[LS_MAX], finished[LS_MAX];
+    int cur, count;
+    const uint8_t *msg, *r, *s, *pkx, *pky;
+    uint64_t *cols;
+    size_t ld, first;
+    uint8_t *err, *flags;
+} lockstep;
+
+static void ls_invmod(w32 *r, const w32 *a, const w32 *m) {
+    lockstep *L = LS;
+    const int k = L->cur;
+    memcpy(L->req[k], a, 32);
+    L->mod[k] = m;
+    L->pending[k] = 1;
+    swapcontext(&L->co[k], &L->main); /* resumed once the group's batch inversion has run */
+    memcpy(r, L->res[k], 32);
+}
+static void ls_entry(void) {
+    lockstep *L = LS;
+    const int k = L->cur;
+    const size_t i = L->first + (size_t)k;
+    walker w = {L->cols, L->ld, i, 0, 0, NULL, 0, 0};
+    uint8_t f = 0;
+    walk_verify(&w, L->msg + 32 * i, L->r + 32 * i, L->s + 32 * i, L->pkx + 32 * i, L->pky + 32 * i, &f);
+    L->err[i] = w.err;
+    if (L->flags) L->flags[i] = f;
+    L->finished[k] = 1; /* returning switches to uc_link = main */
+}
+/* one Fermat ladder for all pending requests with modulus m (they are non-zero: gen_inv filters zero) */
+static void ls_batch_invert(lockstep *L, const w32 *m) {
+    static __thread w32 prefix[LS_MAX][8];
+    int idx[LS_MAX], cnt = 0;
+    for (int k = 0; k < L->count; k++)
+        if (L->pending[k] && L->mod[k] == m) idx[cnt++] = k;
+    if (!cnt) return;
+    w32 acc[8] = {1, 0, 0, 0, 0, 0, 0, 0}, inv[8], t[8];
+    for (int j = 0; j < cnt; j++) {
+        memcpy(prefix[j], acc, 32);
+        fe_mulmod(acc, acc, L->req[idx[j]], m);
+    }
+    fe_invmod(inv, acc, m);
+    for (int j = cnt - 1; j >= 0; j--) {
+        fe_mulmod(L->res[idx[j]], inv, prefix[j], m);
+        fe_mulmod(t, inv, L->req[idx[j]], m);
+        memcpy(inv, t, 32);
+        L->pending[idx[j]] = 0;
+    }
+}
+static void ls_run_group(lockstep *L) {
+    for (int k = 0; k < L->count; k++) {
+        L->pending[k] = L->finished[k] = 0;
+        getcontext(&L->co[k]);
+        L->co[k].uc_stack.ss_sp = L->stack + (size_t)k * LS_STACK;
+        L->co[k].uc_stack.ss_size = LS_STACK;
+        L->co[k].uc_link = &L->main;
+        makecontext(&L->co[k], ls_entry, 0);
+    }
+    for (;;) {
+        int live = 0;
+        for (int k = 0; k < L->count; k++) {
+            if (L->finished[k]) continue;
+            L->cur = k;
+            swapcontext(&L->main, &L->co[k]); /* runs signature k up to its next inverse (or to the end) */
+            live += !L->finished[k];
+        }
+        if (!live) break;
+        ls_batch_invert(L, MOD_P);
+        ls_batch_invert(L, MOD_N);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* batch entry points                                                                           */
 /* ------------------------------------------------------------------------------------------ */
 static void gather(const u64 *base, size_t ld, size_t i, u64 *out, int n) {
@@ -1127,6 +1220,45 @@ long p2e_oracle_verify_witness_aux(const uint8_t *msg, const uint8_t *r, const u
         err[i] = w.err;
         if (flags) flags[i] = f;
     }
+    return count_err(err, n);
+}
+long p2e_oracle_verify_witness_lockstep(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
+                                        const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint8_t *err,
+                                        uint8_t *flags, int nthreads, int group) {
+    oracle_init();
+    if (group < 1) group = 64;
+    if (group > LS_MAX) group = LS_MAX;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+    const size_t ngroups = (n + (size_t)group - 1) / (size_t)group;
+    int failed = 0;
+#pragma omp parallel
+    {
+        lockstep *L = (lockstep *)malloc(sizeof(lockstep));
+        char *stack = (char *)malloc((size_t)group * LS_STACK);
+        if (!L || !stack) {
+#pragma omp atomic write
+            failed = 1;
+        } else {
+            L->stack = stack;
+            L->msg = msg, L->r = r, L->s = s, L->pkx = pkx, L->pky = pky;
+            L->cols = cols, L->ld = ld, L->err = err, L->flags = flags;
+#pragma omp for schedule(dynamic, 1)
+            for (size_t g = 0; g < ngroups; g++) {
+                L->first = g * (size_t)group;
+                L->count = (int)(n - L->first < (size_t)group ? n - L->first : (size_t)group);
+                LS = L;
+                ls_run_group(L);
+                LS = NULL;
+            }
+        }
+        free(stack);
+        free(L);
+    }
+    if (failed) return -1;
     return count_err(err, n);
 }
 long p2e_oracle_glv_mul_witness(const uint8_t *px, const uint8_t *py, const uint8_t *k, uint64_t *cols,

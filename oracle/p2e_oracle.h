@@ -72,6 +72,14 @@ long p2e_oracle_limb_pack(const uint64_t *limbs, uint8_t *packed, size_t n, size
 long p2e_oracle_verify_witness(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
                                const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint8_t *err,
                                uint8_t *flags, int nthreads);
+/* The same columns by the OPTIMISED CPU variant (BASELINE.md section 2 variant b; bench.py cpu_baseline_optimised):
+ * signatures are walked in lock-step groups of `group` (<= 256, <= 0 -> 64) and every inverse generator's
+ * FF::inverse() of a group is one Fermat ladder + 3 multiplications per signature (Montgomery's trick across
+ * signatures at the same schedule step); everything else is the faithful-cost algorithm.  Returns -1 if the
+ * per-thread coroutine stacks cannot be allocated. */
+long p2e_oracle_verify_witness_lockstep(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
+                                        const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint8_t *err,
+                                        uint8_t *flags, int nthreads, int group);
 /* gadgets/glv.rs:87-104 : cols[65243][n] */
 long p2e_oracle_glv_mul_witness(const uint8_t *px, const uint8_t *py, const uint8_t *k, uint64_t *cols,
                                 size_t n, size_t ld, uint8_t *err, uint8_t *flags, int nthreads);

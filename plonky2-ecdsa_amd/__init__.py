@@ -109,6 +109,26 @@ def lib():
     return _lib
 
 
+def _ld(a):
+    """Row stride, in elements, of a 2-D column matrix (numpy or torch): what the C ABI calls `ld`.  A view of a
+    wider matrix (e.g. the padded output of ecdsa_verify_witness_batch) carries its stride with it; the inner
+    (batch) dimension must be dense."""
+    if isinstance(a, np.ndarray):
+        if a.ndim != 2 or (a.shape[1] > 1 and a.strides[1] != a.itemsize):
+            raise P2EError("column matrices must be 2-D with a dense batch dimension")
+        return a.strides[0] // a.itemsize if a.shape[0] > 1 else max(a.shape[1], a.strides[0] // a.itemsize)
+    if a.dim() != 2 or (a.shape[1] > 1 and a.stride(1) != 1):
+        raise P2EError("column matrices must be 2-D with a dense batch dimension")
+    return a.stride(0) if a.shape[0] > 1 else max(a.shape[1], a.stride(0))
+
+
+def _dense(n, *arrays):
+    """the single-generator entry points share ONE ld between inputs and outputs: inputs must be dense (k, n)"""
+    for a in arrays:
+        if _ld(a.reshape(-1, a.shape[-1]) if a.ndim == 3 else a) != n:
+            raise P2EError("pass contiguous (k, n) limb-column arrays")
+
+
 def _ptr(a):
     """device pointer of a torch tensor / host pointer of a numpy array / None"""
     if a is None:
@@ -249,6 +269,7 @@ class Context:
     def mul_witness_batch(self, field, x, y):
         """MulNonnativeGenerator + CheckSumGenerator (gates/mul_nonnative.rs:249-324, :513-531)."""
         n = self._shape(x)[1]
+        _dense(n, x, y)
         r, q, cs, b, err = self._cols(9, n), self._cols(9, n), self._cols(17, n), self._cols(16, n), self._vec(n, np.uint8)
         bad = self._check(self._L.p2e_mul_witness_batch(self._h, C.c_int(field), _ptr(x), _ptr(y), _ptr(r), _ptr(q),
                                                         _ptr(cs), _ptr(b), C.c_size_t(n), C.c_size_t(n), _ptr(err)))
@@ -256,12 +277,14 @@ class Context:
 
     def checksum_witness_batch(self, a):
         n = self._shape(a)[1]
+        _dense(n, a)
         b, err = self._cols(16, n), self._vec(n, np.uint8)
         bad = self._check(self._L.p2e_checksum_witness_batch(self._h, _ptr(a), _ptr(b), C.c_size_t(n), C.c_size_t(n), _ptr(err)))
         return b, err, bad
 
     def _binop(self, fn, field, a, b):
         n = self._shape(a)[1]
+        _dense(n, a, b)
         out, ov, err = self._cols(9, n), self._vec(n), self._vec(n, np.uint8)
         bad = self._check(fn(self._h, C.c_int(field), _ptr(a), _ptr(b), _ptr(out), _ptr(ov), C.c_size_t(n),
                              C.c_size_t(n), _ptr(err)))
@@ -278,6 +301,7 @@ class Context:
     def add_many_witness_batch(self, field, summands):
         """NonNativeMultipleAddsGenerator (gadgets/nonnative.rs:696-728); summands (k, 9, n)."""
         k, _, n = self._shape(summands)
+        _dense(n, summands)
         out, ov, err = self._cols(9, n), self._vec(n), self._vec(n, np.uint8)
         bad = self._check(self._L.p2e_add_many_witness_batch(self._h, C.c_int(field), _ptr(summands), C.c_int(k),
                                                              _ptr(out), _ptr(ov), C.c_size_t(n), C.c_size_t(n), _ptr(err)))
@@ -286,6 +310,7 @@ class Context:
     def inv_witness_batch(self, field, x):
         """NonNativeInverseGenerator (gadgets/nonnative.rs:857-872)."""
         n = self._shape(x)[1]
+        _dense(n, x)
         inv, div, err = self._cols(9, n), self._cols(9, n), self._vec(n, np.uint8)
         bad = self._check(self._L.p2e_inv_witness_batch(self._h, C.c_int(field), _ptr(x), _ptr(inv), _ptr(div),
                                                         C.c_size_t(n), C.c_size_t(n), _ptr(err)))
@@ -296,6 +321,7 @@ class Context:
         (div (max(0, na - nb + 1), n), rem (nb, n), err, flagged)."""
         na, n = self._shape(a)
         nb = self._shape(b)[0]
+        _dense(n, a, b)
         nd = 0 if nb > na + 1 else na - nb + 1
         div, rem, err = self._cols(max(nd, 1), n), self._cols(nb, n), self._vec(n, np.uint8)
         bad = self._check(self._L.p2e_biguint_div_rem_batch(self._h, _ptr(a), C.c_int(na), _ptr(b), C.c_int(nb), _ptr(div),
@@ -305,6 +331,7 @@ class Context:
     def glv_decompose_batch(self, k):
         """GLVDecompositionGenerator (gadgets/glv.rs:128-142)."""
         n = self._shape(k)[1]
+        _dense(n, k)
         k1, k2, n1, n2, err = self._cols(5, n), self._cols(5, n), self._vec(n), self._vec(n), self._vec(n, np.uint8)
         bad = self._check(self._L.p2e_glv_decompose_batch(self._h, _ptr(k), _ptr(k1), _ptr(k2), _ptr(n1), _ptr(n2),
                                                           C.c_size_t(n), C.c_size_t(n), _ptr(err)))
@@ -314,25 +341,26 @@ class Context:
         """set_biguint_target (gadgets/biguint.rs:454-463): (n, 32) uint8 -> (9, n) limb columns."""
         n = self._shape(packed)[0]
         limbs = out if out is not None else self._cols(9, n)
-        self._check(self._L.p2e_limb_split(self._h, _ptr(packed), _ptr(limbs), C.c_size_t(n), C.c_size_t(self._shape(limbs)[1])))
+        self._check(self._L.p2e_limb_split(self._h, _ptr(packed), _ptr(limbs), C.c_size_t(n), C.c_size_t(_ld(limbs))))
         return limbs
 
     def limb_pack(self, limbs):
         """get_biguint_target (gadgets/biguint.rs:444-452): (9, n) limb columns -> (n, 32) uint8."""
         n = self._shape(limbs)[1]
+        ld = _ld(limbs)
         if self.host_pointers:
             packed = np.zeros((n, 32), dtype=np.uint8)
         else:
             import torch
             packed = torch.empty((n, 32), dtype=torch.uint8, device=f"cuda:{self.device}")
         err = self._vec(n, np.uint8)
-        bad = self._check(self._L.p2e_limb_pack(self._h, _ptr(limbs), _ptr(packed), C.c_size_t(n), C.c_size_t(n), _ptr(err)))
+        bad = self._check(self._L.p2e_limb_pack(self._h, _ptr(limbs), _ptr(packed), C.c_size_t(n), C.c_size_t(ld), _ptr(err)))
         return packed, err, bad
 
     def columns_to_rows(self, cols, n=None, ld=None, rows=None):
         """(ncols, ld) column-major matrix -> (n, ncols) matrix with one contiguous witness per signature."""
         ncols = self._shape(cols)[0]
-        ld = ld if ld is not None else self._shape(cols)[1]
+        ld = ld if ld is not None else _ld(cols)
         n = n if n is not None else self._shape(cols)[1]
         if rows is None:
             if self.host_pointers:
@@ -341,7 +369,7 @@ class Context:
                 import torch
                 rows = torch.empty((n, ncols), dtype=torch.int64, device=f"cuda:{self.device}")
         self._check(self._L.p2e_columns_to_rows(self._h, _ptr(cols), C.c_size_t(ld), C.c_size_t(n), C.c_size_t(ncols),
-                                                _ptr(rows), C.c_size_t(self._shape(rows)[1])))
+                                                _ptr(rows), C.c_size_t(_ld(rows))))
         return rows
 
     def compact_to_rows(self, program, narrow, wide, n, ld_narrow=None, ld_wide=None, rows_narrow=None, rows_wide=None):
@@ -355,10 +383,10 @@ class Context:
                 dev = f"cuda:{self.device}"
                 rows_narrow = torch.empty((n, nn), dtype=torch.int32, device=dev)
                 rows_wide = torch.empty((n, nw), dtype=torch.int64, device=dev)
-        self._check(self._L.p2e_compact_to_rows(self._h, C.c_int(program), _ptr(narrow), C.c_size_t(ld_narrow or self._shape(narrow)[1]),
-                                                _ptr(wide), C.c_size_t(ld_wide or self._shape(wide)[1]), C.c_size_t(n),
-                                                _ptr(rows_narrow), C.c_size_t(self._shape(rows_narrow)[1]), _ptr(rows_wide),
-                                                C.c_size_t(self._shape(rows_wide)[1])))
+        self._check(self._L.p2e_compact_to_rows(self._h, C.c_int(program), _ptr(narrow), C.c_size_t(ld_narrow or _ld(narrow)),
+                                                _ptr(wide), C.c_size_t(ld_wide or _ld(wide)), C.c_size_t(n),
+                                                _ptr(rows_narrow), C.c_size_t(_ld(rows_narrow)), _ptr(rows_wide),
+                                                C.c_size_t(_ld(rows_wide))))
         return rows_narrow, rows_wide
 
     # ---- fused schedules -----------------------------------------------------------------------------
@@ -373,7 +401,7 @@ class Context:
             cols = full[:, :n] if ld != n else full
         err = err if err is not None else self._vec(n, np.uint8)
         valid = valid if valid is not None else self._vec(n, np.uint8)
-        ld = ld if ld is not None else self._shape(cols)[1]
+        ld = ld if ld is not None else _ld(cols)
         bad = self._check(self._L.p2e_ecdsa_verify_witness_batch(self._h, _ptr(msg), _ptr(r), _ptr(s), _ptr(pkx), _ptr(pky),
                                                                  _ptr(cols), C.c_size_t(n), C.c_size_t(ld), _ptr(err), _ptr(valid)))
         return cols, err, valid, bad
@@ -382,10 +410,10 @@ class Context:
         """Built-in-generator columns (bool selects, window bits / digits, random-access selections, is_equal / not
         results: SURVEY.md 8(f) rank 1) derived from a finished witness matrix: (8959 | 4738, n) columns."""
         n = n if n is not None else self._shape(pky)[0]
-        ld = ld if ld is not None else self._shape(cols)[1]
+        ld = ld if ld is not None else _ld(cols)
         if aux is None:
             aux = self._cols(VERIFY_AUX_COLS if program == PROGRAM_VERIFY else GLV_MUL_AUX_COLS, n)
-        ld_aux = ld_aux if ld_aux is not None else self._shape(aux)[1]
+        ld_aux = ld_aux if ld_aux is not None else _ld(aux)
         err = err if err is not None else self._vec(n, np.uint8)
         bad = self._check(self._L.p2e_aux_witness_batch(self._h, C.c_int(program), _ptr(pky), _ptr(cols), C.c_size_t(ld),
                                                         _ptr(aux), C.c_size_t(ld_aux), C.c_size_t(n), _ptr(err)))
@@ -395,7 +423,7 @@ class Context:
         """Repack a finished witness matrix for transfers: (narrow u32 (num_narrow, n), wide u64 (num_wide, n), err, bad).
         Preallocated `narrow` / `wide` may be column slices of wider matrices: pass their row strides."""
         _m, nn, nw = compact_layout(program)
-        ld = ld if ld is not None else self._shape(cols)[1]
+        ld = ld if ld is not None else _ld(cols)
         n = n if n is not None else self._shape(cols)[1]
         if narrow is None or wide is None:
             if self.host_pointers:
@@ -407,8 +435,8 @@ class Context:
                 wide = torch.empty((nw, n), dtype=torch.int64, device=dev)
         err = err if err is not None else self._vec(n, np.uint8)
         bad = self._check(self._L.p2e_columns_compact(self._h, C.c_int(program), _ptr(cols), C.c_size_t(ld), C.c_size_t(n),
-                                                      _ptr(narrow), C.c_size_t(ld_narrow or self._shape(narrow)[1]), _ptr(wide),
-                                                      C.c_size_t(ld_wide or self._shape(wide)[1]), _ptr(err)))
+                                                      _ptr(narrow), C.c_size_t(ld_narrow or _ld(narrow)), _ptr(wide),
+                                                      C.c_size_t(ld_wide or _ld(wide)), _ptr(err)))
         return narrow, wide, err, bad
 
     def ecdsa_verify_batch(self, msg, r, s, pkx, pky, err=None, valid=None):
@@ -431,7 +459,9 @@ class Context:
                 dev = f"cuda:{self.device}"
                 narrow = torch.empty((nn, ldp), dtype=torch.int32, device=dev)
                 wide = torch.empty((nw, ldp), dtype=torch.int64, device=dev)
-        return narrow, wide, ld_narrow or self._shape(narrow)[1], ld_wide or self._shape(wide)[1]
+            # same convention as ecdsa_verify_witness_batch: (k, n) views whose row stride is the padded one
+            narrow, wide = narrow[:, :n], wide[:, :n]
+        return narrow, wide, ld_narrow or _ld(narrow), ld_wide or _ld(wide)
 
     def ecdsa_verify_witness_compact_batch(self, msg, r, s, pkx, pky, narrow=None, wide=None, err=None, valid=None,
                                            ld_narrow=None, ld_wide=None):
@@ -458,7 +488,7 @@ class Context:
     def aux_witness_compact_batch(self, program, pky, narrow, n=None, ld_narrow=None, aux32=None, err=None, ld_aux=None):
         """aux_witness_batch inside the compact container: reads the narrow u32 matrix, writes a u32 aux matrix."""
         n = n if n is not None else self._shape(pky)[0]
-        ld_narrow = ld_narrow if ld_narrow is not None else self._shape(narrow)[1]
+        ld_narrow = ld_narrow if ld_narrow is not None else _ld(narrow)
         if aux32 is None:
             k = VERIFY_AUX_COLS if program == PROGRAM_VERIFY else GLV_MUL_AUX_COLS
             if self.host_pointers:
@@ -466,7 +496,7 @@ class Context:
             else:
                 import torch
                 aux32 = torch.empty((k, n), dtype=torch.int32, device=f"cuda:{self.device}")
-        ld_aux = ld_aux if ld_aux is not None else self._shape(aux32)[1]
+        ld_aux = ld_aux if ld_aux is not None else _ld(aux32)
         err = err if err is not None else self._vec(n, np.uint8)
         bad = self._check(self._L.p2e_aux_witness_compact_batch(self._h, C.c_int(program), _ptr(pky), _ptr(narrow),
                                                                 C.c_size_t(ld_narrow), _ptr(aux32), C.c_size_t(ld_aux),
@@ -479,7 +509,7 @@ class Context:
         cols = cols if cols is not None else self._cols(GLV_MUL_COLS, n)
         err = err if err is not None else self._vec(n, np.uint8)
         valid = valid if valid is not None else self._vec(n, np.uint8)
-        ld = ld if ld is not None else self._shape(cols)[1]
+        ld = ld if ld is not None else _ld(cols)
         bad = self._check(self._L.p2e_glv_mul_witness_batch(self._h, _ptr(px), _ptr(py), _ptr(k), _ptr(cols),
                                                             C.c_size_t(n), C.c_size_t(ld), _ptr(err), _ptr(valid)))
         return cols, err, valid, bad

@@ -326,6 +326,22 @@ static void set_error(const std::string& s) { g_last_error = s; }
         }                                                                                    \
     } while (0)
 
+// Entry points run on the context's device and leave the caller's current device as they found it (a multi-GPU
+// process, or torch, keeps its own notion of "current device").
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int device) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != device) prev = cur;
+        (void)hipSetDevice(device);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct DeviceProgram {
     Program prog;
     OpDesc* d_ops = nullptr;        // with the run marks of ctx->run_iters (F_NO_AFFINE)
@@ -362,7 +378,7 @@ struct p2e_ctx {
     // one event pair around every expansion launch; kind 0 = k_expand (op by op), 1 = k_expand_runs
     static constexpr int MAX_EXPAND = 2 * MAX_SEG;
     hipEvent_t ev_c0[MAX_EXPAND] = {}, ev_c1[MAX_EXPAND] = {};
-    int n_expand = 0;
+    int n_expand = 0, n_seg = 0;
     double expand_cols[MAX_EXPAND] = {};
     int expand_kind[MAX_EXPAND] = {};
     int msm_pieces = 8, fixed_pieces = 2;   // one Montgomery inversion batch per piece
@@ -474,10 +490,17 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         set_error("device index out of range");
         return P2E_E_INVALID;
     }
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);
     p2e_ctx* c = new p2e_ctx();
     c->device = device;
     c->flags = flags;
+    // a failing HIP call below must not leak the context and what it already owns
+    struct Cleanup {
+        p2e_ctx* c;
+        ~Cleanup() {
+            if (c) p2e_ctx_destroy(c);
+        }
+    } cleanup{c};
     if (stream) {
         c->stream = (hipStream_t)stream;
     } else {
@@ -541,14 +564,15 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         int v = atoi(env);
         if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->fixed_pieces = v;
     }
+    cleanup.c = nullptr;
     *out = c;
     return 0;
 }
 
 extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    DeviceGuard guard(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_cpts);
     (void)hipFree(c->d_fbtab);
     for (auto& p : c->progs) {
@@ -583,16 +607,38 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
     delete c;
 }
 
+// Which part of the fused pipeline an asynchronous failure (a kernel fault surfaces only when a stream is
+// synchronised) had reached: the first recorded event of the call that did not complete.
+static std::string pipeline_progress(p2e_ctx* c) {
+    if (!c->have_phases) return "single-kernel call";
+    if (hipEventQuery(c->ev[1]) != hipSuccess) return "scalar phase (k_scalar)";
+    for (int k = 0; k < c->n_seg; k++) {
+        if (hipEventQuery(c->ev_piece[k]) != hipSuccess) return "phase A (k_chains), chain piece " + std::to_string(k);
+        if (hipEventQuery(c->ev_binv[k]) != hipSuccess) return "phase B (k_batch_inv), chain piece " + std::to_string(k);
+    }
+    for (int k = 0; k < c->n_expand; k++)
+        if (hipEventQuery(c->ev_c1[k]) != hipSuccess)
+            return std::string("phase C (") + (c->expand_kind[k] ? "k_expand_runs" : "k_expand") + "), launch " + std::to_string(k);
+    return "finalisation";
+}
+
 extern "C" int p2e_sync(p2e_ctx* c) {
     if (!c) return P2E_E_INVALID;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    DeviceGuard guard(c->device);
+    hipError_t se = hipStreamSynchronize(c->stream);
+    if (se != hipSuccess) {
+        const std::string where = pipeline_progress(c);
+        set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(se) + " [asynchronous failure; reached: " + where + "]");
+        (void)hipGetLastError();
+        return P2E_E_HIP;
+    }
     if (c->have_phases) {
-        (void)hipEventElapsedTime(&c->phase_ms[0], c->ev[0], c->ev[1]);   // scalar kernel
-        (void)hipEventElapsedTime(&c->phase_ms[4], c->ev[0], c->ev[5]);   // whole call
+        HIP_TRY(hipEventElapsedTime(&c->phase_ms[0], c->ev[0], c->ev[1]));   // scalar kernel
+        HIP_TRY(hipEventElapsedTime(&c->phase_ms[4], c->ev[0], c->ev[5]));   // whole call
         double cnt[2] = {0, 0}, cols[2] = {0, 0}, sum_ms[2] = {0, 0};
         for (int k = 0; k < c->n_expand; k++) {
             float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, c->ev_c0[k], c->ev_c1[k]);
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev_c0[k], c->ev_c1[k]));
             const int kind = c->expand_kind[k];
             cnt[kind] += 1;
             cols[kind] += c->expand_cols[k];
@@ -625,7 +671,9 @@ static int ensure_scratch(p2e_ctx* c, size_t bytes) {
     }
     hipError_t e = hipMalloc(&c->scratch, bytes);
     if (e != hipSuccess) {
-        set_error("scratch allocation failed");
+        c->scratch = nullptr;
+        (void)hipGetLastError();   // handled here: must not resurface as the next call's "kernel launch" error
+        set_error("scratch allocation of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
         return P2E_E_NOMEM;
     }
     c->scratch_bytes = bytes;
@@ -648,6 +696,7 @@ static long finish_call(p2e_ctx* c) {
 // ---- host-pointer staging (slow path, used by ctypes-only callers) ----------------------------------
 struct Staged {
     p2e_ctx* c;
+    DeviceGuard guard;
     std::vector<void*> dev;
     struct Out {
         void* host;
@@ -656,40 +705,75 @@ struct Staged {
     };
     std::vector<Out> outs;
     bool host;
+    bool finished = false;
     int rc = 0;
-    explicit Staged(p2e_ctx* ctx) : c(ctx), host((ctx->flags & P2E_CTX_HOST_POINTERS) != 0) {}
-    template <class T>
-    const T* in(const T* p, size_t bytes) {
-        if (!host || !p) return p;
+    explicit Staged(p2e_ctx* ctx) : c(ctx), guard(ctx->device), host((ctx->flags & P2E_CTX_HOST_POINTERS) != 0) {}
+    Staged(const Staged&) = delete;
+    Staged& operator=(const Staged&) = delete;
+    void* stage(size_t bytes) {
         void* d = nullptr;
-        if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) {
+        hipError_t e = hipMalloc(&d, bytes ? bytes : 1);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();   // handled: must not resurface as the next call's launch error
+            if (!rc) set_error("staging allocation of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
             rc = P2E_E_NOMEM;
             return nullptr;
         }
         dev.push_back(d);
-        if (hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = P2E_E_HIP;
+        return d;
+    }
+    template <class T>
+    const T* in(const T* p, size_t bytes) {
+        if (!host || !p) return p;
+        if (rc) return nullptr;        // an earlier buffer failed: do not touch the host side again
+        void* d = stage(bytes);
+        if (!d) return nullptr;
+        hipError_t e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error(std::string("staging copy to the device failed: ") + hipGetErrorString(e));
+            rc = P2E_E_HIP;
+        }
         return (const T*)d;
     }
     template <class T>
     T* out(T* p, size_t bytes) {
         if (!host || !p) return p;
-        void* d = nullptr;
-        if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) {
-            rc = P2E_E_NOMEM;
-            return nullptr;
-        }
-        dev.push_back(d);
+        if (rc) return nullptr;
+        void* d = stage(bytes);
+        if (!d) return nullptr;
         outs.push_back({p, d, bytes});
         return (T*)d;
     }
-    long done(long r) {
-        if (host) {
-            for (auto& o : outs)
-                if (hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) r = P2E_E_HIP;
+    // every exit of a staged entry point ends here: done(r) on the normal paths, the destructor on early error
+    // returns (HIP_TRY / ZERO_COUNTER).  A failed call may have queued work on the internal streams: nothing of
+    // it may still be running when the staged buffers are freed or the scratch is reused by the next call.
+    void release(bool failed) {
+        if (failed) {
+            for (hipStream_t st : {c->st_msm, c->st_fixed})
+                if (st) (void)hipStreamSynchronize(st);
             (void)hipStreamSynchronize(c->stream);
-            for (void* d : dev) (void)hipFree(d);
+            (void)hipGetLastError();
         }
+        if (!dev.empty()) {
+            if (!failed) (void)hipStreamSynchronize(c->stream);
+            for (void* d : dev) (void)hipFree(d);
+            dev.clear();
+        }
+        finished = true;
+    }
+    long done(long r) {
+        if (host && r >= 0)
+            for (auto& o : outs)
+                if (hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+                    set_error("staging copy to the host failed");
+                    r = P2E_E_HIP;
+                }
+        release(r < 0);
         return r;
+    }
+    ~Staged() {
+        if (!finished) release(true);
     }
 };
 
@@ -702,7 +786,6 @@ static bool bad_common(p2e_ctx* c, size_t n, size_t ld) {
         set_error("ld < n");
         return true;
     }
-    (void)hipSetDevice(c->device);
     return false;
 }
 static inline dim3 grid1(size_t n) { return dim3((unsigned)((n + BS - 1) / BS)); }
@@ -1018,6 +1101,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         }
     }
     if (verify) segs[ns - 1].final_after = true;
+    c->n_seg = ns;
 
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (gx_wide) LAUNCH_EMIT(k_scalar, true, dim3(gx_wide), c->stream, G, B, (size_t)0);

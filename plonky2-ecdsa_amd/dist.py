@@ -29,22 +29,73 @@ def shard_of(j: int, total: int, world: int):
     return rem + (j - cut) // base, (j - cut) % base
 
 
-def all_gather_columns(local, total: int, group=None):
-    """local: (cols, n_local) int64/uint64 tensor of this rank's shard.  Returns (world, cols, n_max)
-    where n_max = max shard size (shards shorter than n_max are zero padded on the right)."""
+def _dense_base(local):
+    """The dense (cols, ld) matrix a column-slice view (cols, n <= ld) lives in, without copying; None if the view
+    is not of that shape (then the caller packs it)."""
+    import torch
+
+    cols, n = local.shape
+    if n > 1 and local.stride(1) != 1:
+        return None
+    ld = local.stride(0) if cols > 1 else n
+    if ld == n:
+        return local if local.is_contiguous() else None
+    if ld < n:
+        return None
+    have = local.untyped_storage().nbytes() // local.element_size() - local.storage_offset()
+    if have < cols * ld:
+        return None
+    return torch.as_strided(local, (cols, ld), (ld, 1))
+
+
+def gather_buffer(local, world: int):
+    """An output buffer all_gather_columns can reuse across calls (same shape rules as the call itself)."""
+    import torch
+
+    base = _dense_base(local)
+    rows, ld = (base.shape if base is not None else local.shape)
+    return torch.empty((world * rows, ld), dtype=local.dtype, device=local.device)
+
+
+def all_gather_columns(local, total: int, group=None, n_local=None, out=None):
+    """local: this rank's shard of the column matrix, (cols, n_local) int64/uint64/int32 -- typically the
+    ``[:, :n]`` view of a padded (cols, ld) output buffer of the fused entry points, which is gathered AS IS (one
+    all_gather_into_tensor straight from the buffer, no packing copy: 43 GB at 2^16) whenever every rank has the same
+    ld; the pad columns are dropped from the result by a view.  ``n_local`` (default: this rank's shard size from
+    shard_bounds) is the number of valid signatures in ``local``; a wider ``local`` (an unsliced padded buffer) is
+    accepted and sliced.  Returns (world, cols, n_max) with n_max = the largest shard; shorter shards are padded on
+    the right (zeros on the packing path, the buffer's own pad otherwise)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     n_max = -(-total // world)
-    cols, n_local = local.shape
-    if n_local != n_max:
-        padded = torch.zeros((cols, n_max), dtype=local.dtype, device=local.device)
-        padded[:, :n_local] = local
-        local = padded
-    out = torch.empty((world * cols, n_max), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)  # concatenation along dim 0
-    return out.view(world, cols, n_max)
+    if n_local is None:
+        s, e = shard_bounds(total, rank, world)
+        n_local = e - s
+    if n_local > n_max or n_local > local.shape[1]:
+        raise ValueError(f"n_local {n_local} exceeds the largest shard {n_max} or the matrix ({local.shape[1]} columns)")
+    local = local[:, :n_local]
+    cols = local.shape[0]
+    base = _dense_base(local)
+    ld = base.shape[1] if base is not None else -1
+    if ld < n_max:
+        ld = -1
+    # the no-copy path needs ONE ld on all ranks: agree on it (a two-element all-reduce)
+    probe = torch.tensor([ld, -ld], dtype=torch.int64, device=local.device)
+    dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
+    same_ld = int(probe[0]) == ld and int(probe[1]) == -ld and ld > 0
+    if same_ld:
+        src = base
+    else:
+        ld = n_max
+        src = torch.zeros((cols, n_max), dtype=local.dtype, device=local.device)
+        src[:, :n_local] = local
+    if out is None or tuple(out.shape) != (world * cols, ld) or out.dtype != local.dtype:
+        out = torch.empty((world * cols, ld), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, src, group=group)  # concatenation along dim 0
+    return out.view(world, cols, ld)[:, :, :n_max]
 
 
 def global_column(gathered, col: int, total: int):

@@ -47,6 +47,23 @@ def _worker(rank, world, port, total, q):
         for j in range(total):
             r, i = pd.shard_of(j, total, world)
             ok = ok and np.array_equal(gathered[r, :, i].numpy().view(np.uint64), want[:, j])
+    # the shard as the fused entry points leave it: the [:, :n] view of a padded (cols, n + pad) buffer, and that
+    # buffer unsliced with n_local given.  Equal shards gather straight from the buffer (no packing copy), unequal
+    # ones are packed; either way the result is the same matrix.
+    n_local = end - start
+    big = torch.full((p2e.VERIFY_COLS, n_local + 3), -1, dtype=torch.int64)
+    big[:, :n_local] = local
+    g2 = pd.all_gather_columns(big[:, :n_local], total)
+    g3 = pd.all_gather_columns(big, total, n_local=n_local, out=pd.gather_buffer(big[:, :n_local], world))
+    ok = ok and g2.shape == gathered.shape and g3.shape == gathered.shape
+    for r in range(world):
+        s_, e_ = pd.shard_bounds(total, r, world)
+        ok = ok and torch.equal(g2[r, :, :e_ - s_], gathered[r, :, :e_ - s_]) and torch.equal(g3[r, :, :e_ - s_], gathered[r, :, :e_ - s_])
+    try:
+        pd.all_gather_columns(big, total, n_local=n_local + 4)
+        ok = False
+    except ValueError:
+        pass
     # the same assembly in the compact container (u32 narrow + u64 wide matrices)
     cmap, nn, nw = p2e.compact_layout(0)
     narrow, wide, cerr, _ = EmuBackend().compact(0, sigs, nn, nw)
@@ -77,8 +94,9 @@ def test_shard_bounds_cover_batch():
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_gloo_shard_and_gather():
-    world, total = 2, 5   # uneven shards: 3 + 2
+@pytest.mark.parametrize("total", [5, 4], ids=["uneven_3_2", "even_2_2"])
+def test_two_rank_gloo_shard_and_gather(total):
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -466,3 +466,106 @@ def test_gpu_output_passes_the_constraint_replay():
     for i in (1, 298):
         px, py = CC.unpack_inputs(sigs[3:5], i)
         CC.check_glv_mul(ghost[:, i], px, py, ks[i])
+
+
+@pytest.mark.parametrize("container", ["u64", "compact", "rows"])
+def test_cfg5_streamed_chunks(container):
+    """BASELINE config 5 (witness columns streamed to the host prover; one GPU's leg of it): 2^16 + 300 signatures in
+    2^13-signature chunks through the double-buffered D2H pipeline (plonky2_ecdsa_amd.stream.HostStreamer), the last
+    chunk ragged.  EVERY chunk is compared with the oracle on the HOST copy (first / middle / last signature of the chunk,
+    every column), all signatures verify, nothing is flagged."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    from plonky2_ecdsa_amd.stream import HostStreamer
+    chunk, total = 1 << 13, (1 << 16) + 300
+    sigs = p2e.synth_signatures(seed=5, n=total)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    hs = HostStreamer(device=0, chunk=chunk, container=container)
+    seen = []
+
+    def consumer(ch):
+        idx = np.unique(np.array([0, ch.n // 2, ch.n - 1]))
+        want, werr, wflags = oracle_c.verify_witness(*[a[ch.first + idx] for a in sigs])
+        if container == "compact":
+            got = p2e.compact_expand(0, ch.narrow[:, idx].contiguous().numpy().view(np.uint32), ch.wide[:, idx].contiguous().numpy())
+        elif container == "rows":
+            got = ch.rows[idx].t().contiguous().numpy().view(np.uint64)
+        else:
+            got = ch.cols[:, idx].contiguous().numpy().view(np.uint64)
+        assert np.array_equal(got, want), f"chunk {ch.index}: host copy differs from the oracle"
+        assert not ch.err.any() and ch.valid.all() and not werr.any() and wflags.all()
+        seen.append((ch.index, ch.first, ch.n))
+
+    st = hs.run(dev, consumer)
+    assert seen == [(k, k * chunk, min(chunk, total - k * chunk)) for k in range(9)] and seen[-1][2] == 300
+    assert st["flagged"] == 0 and st["valid"] == total and st["chunks"] == 9
+
+
+def test_default_strides_follow_the_array():
+    """the default output of ecdsa_verify_witness_batch at a power-of-two n >= 4096 is a (82615, n) VIEW of a
+    padded matrix (row stride n + 16).  Every helper that takes it must read its stride from the array."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    n = 4096
+    sigs = p2e.synth_signatures(seed=404, n=n)
+    ctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    cols, _err, valid, bad = ctx.ecdsa_verify_witness_batch(*dev)
+    assert bad == 0 and cols.shape == (p2e.VERIFY_COLS, n) and cols.stride(0) == n + 16
+    idx = np.array([0, 1, 2047, 4095])
+    want, waux, _, _ = oracle_c.verify_witness_aux(*[a[idx] for a in sigs])
+    rows = ctx.columns_to_rows(cols)                                   # default ld
+    aux, _aerr, abad = ctx.aux_witness_batch(0, dev[4], cols)          # default n, ld, ld_aux
+    nar, wid, _cerr, cbad = ctx.columns_compact(0, cols)               # default n, ld
+    fnar, fwid, _e, fvalid, fbad = ctx.ecdsa_verify_witness_compact_batch(*dev)   # sliced like the u64 output
+    faux, _e2, fabad = ctx.aux_witness_compact_batch(0, dev[4], fnar)
+    torch.cuda.synchronize()
+    assert abad == cbad == fbad == fabad == 0 and int(fvalid.sum()) == n
+    tidx = torch.from_numpy(idx).cuda()
+    assert np.array_equal(rows[tidx].t().cpu().numpy().view(np.uint64), want)
+    assert np.array_equal(aux[:, tidx].cpu().numpy().view(np.uint64), waux)
+    assert fnar.shape[1] == n and fwid.shape[1] == n and fnar.stride(0) == n + 16
+    for a, b in ((nar, wid), (fnar, fwid)):
+        got = p2e.compact_expand(0, a[:, tidx].cpu().numpy().view(np.uint32), b[:, tidx].cpu().numpy())
+        assert np.array_equal(got, want)
+    assert np.array_equal(faux[:, tidx].cpu().numpy().view(np.uint32).astype(np.uint64), waux)
+    with pytest.raises(p2e.P2EError):
+        ctx.columns_to_rows(cols.t())                                  # batch dimension not dense
+
+
+def test_failed_calls_clean_up_and_the_context_survives():
+    """Failure paths of the boundary: a staged (host-pointer) call that cannot allocate returns P2E_E_NOMEM without
+    touching the host buffers or crashing, leaks nothing that blocks the next call, and a following valid call on the
+    same context succeeds; the same for a device-pointer call whose scratch does not fit."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    c = p2e.C
+    n = 300
+    sigs = p2e.synth_signatures(seed=77, n=n)
+    want, _, _ = oracle_c.verify_witness(*[a[:4] for a in sigs])
+    hctx = p2e.Context(device=0, host_pointers=True)
+    huge = 1 << 44                                                     # 2^44 * 32 B of staging: cannot exist
+    small = np.zeros((4, 32), dtype=np.uint8)
+    out, e = np.zeros((p2e.VERIFY_COLS, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint8)
+    rc = hctx._L.p2e_ecdsa_verify_witness_batch(hctx._h, *[p2e._ptr(small)] * 5, p2e._ptr(out), c.c_size_t(huge), c.c_size_t(huge),
+                                                p2e._ptr(e), p2e._ptr(e))
+    assert rc == -4 and b"allocation" in hctx._L.p2e_last_error()      # P2E_E_NOMEM
+    x = np.zeros((9, 4), dtype=np.uint64)
+    rc = hctx._L.p2e_inv_witness_batch(hctx._h, c.c_int(0), p2e._ptr(x), p2e._ptr(x), p2e._ptr(x), c.c_size_t(huge), c.c_size_t(huge),
+                                       p2e._ptr(e))
+    assert rc == -4
+    got, err, valid, bad = hctx.ecdsa_verify_witness_batch(*[a[:4] for a in sigs])
+    assert bad == 0 and valid.all() and np.array_equal(np.asarray(got).view(np.uint64), want)
+    # device pointers: the scratch for 2^40 signatures does not fit the HBM
+    dctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    cols = torch.empty((p2e.VERIFY_COLS, 4), dtype=torch.int64, device="cuda")
+    de = torch.empty(4, dtype=torch.uint8, device="cuda")
+    rc = dctx._L.p2e_ecdsa_verify_witness_batch(dctx._h, *[p2e._ptr(d) for d in dev], p2e._ptr(cols), c.c_size_t(1 << 40),
+                                                c.c_size_t(1 << 40), p2e._ptr(de), p2e._ptr(de))
+    assert rc == -4
+    got, err, valid, bad = dctx.ecdsa_verify_witness_batch(*dev)
+    torch.cuda.synchronize()
+    assert bad == 0 and int(valid.sum()) == n and np.array_equal(got[:, :4].cpu().numpy().view(np.uint64), want)
+    # the caller's current device is left alone (single-GPU box: still 0) and the library reports a sane status
+    assert torch.cuda.current_device() == 0 and dctx.sync() == 0

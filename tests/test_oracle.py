@@ -128,3 +128,19 @@ def test_error_semantics():
     x = oracle_c.limbs_cols([0, R.P, 5])
     inv, div, err = be.inv(0, x)
     assert list(err) == [R.ERR_INVERSE_OF_ZERO, R.ERR_INVERSE_OF_ZERO, 0]
+
+
+def test_optimised_cpu_variant_is_bit_identical():
+    """bench.py's cpu_baseline_optimised (lock-step groups, Montgomery batch inversion across signatures) writes the
+    same columns as the faithful-cost walk, also when an element drops out of lock step (s = 0: its inverse generator
+    flags instead of asking for an inversion) and for a group size that does not divide the batch."""
+    import plonky2_ecdsa_amd as p2e
+    arrs = [a.copy() for a in p2e.synth_signatures(seed=12, n=41)]
+    arrs[2][5] = 0            # s = 0
+    arrs[1][7, 0] ^= 1        # does not verify
+    a = oracle_c.verify_witness(*arrs)
+    for group in (1, 16, 64):
+        b = oracle_c.verify_witness_lockstep(*arrs, nthreads=3, group=group)
+        ok = a[1] == 0
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[0][:, ok], b[0][:, ok])
+    assert a[1][5] == R.ERR_INVERSE_OF_ZERO and a[2][7] == 0
