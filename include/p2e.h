@@ -217,6 +217,29 @@ typedef struct p2e_gen_desc {
 /* program 0 = verify circuit, 1 = glv_mul.  Writes up to cap entries; returns the total count. */
 long p2e_schedule_describe(int program, p2e_gen_desc *out, size_t cap);
 long p2e_schedule_num_cols(int program);
+/* Operand wiring of generator g (same index as p2e_schedule_describe): where the targets the gadget passed to it live.
+ * This is what the reference fixes by handing targets from one CircuitBuilderNonNative call to the next
+ * (gadgets/curve.rs:160-243, gadgets/glv.rs:53-104, gadgets/ecdsa.rs:30-53); the Rust side has it as Target lists
+ * (dependencies(), gadgets/nonnative.rs:618-624), a batch consumer needs it as columns.  src[k]:
+ *   c < 2^29                     first limb column c of the witness matrix (limbs in consecutive columns)
+ *   P2E_SRC_AUX | c              column c of the built-in-generator matrix (a mul_biguint_by_bool product, a
+ *                                random_access_curve_points selection: p2e_aux_witness_batch)
+ *   P2E_SRC_INPUT | slot         a caller input: 0 pk.y, 1 pk.x, 2 msg (glv_mul: k), 3 r, 4 s (9-limb virtual targets)
+ *   P2E_SRC_CONST | id           a circuit constant (constant_biguint, gadgets/biguint.rs:165-175): p2e_wiring_const
+ * num_limbs[k]: limbs that target has (constants: convert_base's count, zero has none -- quirk Q5; k1, k2: 5).
+ * range_check: the gadget's range_check flag (one more cmp_biguint in its constraint block, nonnative.rs:180-190). */
+#define P2E_SRC_AUX 0x20000000u
+#define P2E_SRC_INPUT 0x40000000u
+#define P2E_SRC_CONST 0x80000000u
+typedef struct p2e_gen_wiring {
+    int32_t num_operands; /* add, sub: 2; add_many: 4; mul: 2; inv: 1; glv: 1 */
+    uint32_t src[4];
+    uint8_t num_limbs[4];
+    int32_t range_check;
+} p2e_gen_wiring;
+long p2e_schedule_wiring(int program, p2e_gen_wiring *out, size_t cap);
+/* value of constant `id` as 32 little-endian bytes; returns its limb count (0 for the zero constant), < 0: unknown id */
+int p2e_wiring_const(uint32_t id, uint8_t out32[32]);
 
 /* ---- synthetic inputs (host only): valid signatures per curve/ecdsa.rs:25-40 sign_message with
  * sk, msg, nonce drawn from splitmix64(seed, i).  Host buffers of n*32 bytes each. -------------------- */

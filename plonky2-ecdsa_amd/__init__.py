@@ -47,7 +47,7 @@ EXPORTS = (
     "p2e_mul_witness_batch", "p2e_checksum_witness_batch", "p2e_add_witness_batch", "p2e_sub_witness_batch",
     "p2e_add_many_witness_batch", "p2e_inv_witness_batch", "p2e_glv_decompose_batch", "p2e_limb_split",
     "p2e_limb_pack", "p2e_ecdsa_verify_witness_batch", "p2e_glv_mul_witness_batch", "p2e_columns_to_rows",
-    "p2e_schedule_describe",
+    "p2e_schedule_describe", "p2e_schedule_wiring", "p2e_wiring_const",
     "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
     "p2e_compact_layout", "p2e_columns_compact", "p2e_ecdsa_verify_witness_compact_batch",
     "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch", "p2e_compact_to_rows", "p2e_ecdsa_verify_batch", "p2e_biguint_div_rem_batch",
@@ -146,6 +146,34 @@ def schedule_describe(program: int = PROGRAM_VERIFY):
     L.p2e_schedule_describe(C.c_int(program), arr, C.c_size_t(n))
     kinds = ("add", "sub", "add_many", "mul", "inv", "glv")
     return [(kinds[d.kind], d.field, d.first_col, d.num_cols, d.label.decode()) for d in arr]
+
+
+SRC_AUX, SRC_INPUT, SRC_CONST = 0x20000000, 0x40000000, 0x80000000
+INPUT_SLOTS = ("pky", "pkx", "msg", "r", "s")
+
+
+class _GenWiring(C.Structure):
+    _fields_ = [("num_operands", C.c_int32), ("src", C.c_uint32 * 4), ("num_limbs", C.c_uint8 * 4), ("range_check", C.c_int32)]
+
+
+def schedule_wiring(program: int = PROGRAM_VERIFY):
+    """Operand wiring per generator (include/p2e.h p2e_schedule_wiring): list of ([(src, num_limbs), ...], range_check)
+    in the order of schedule_describe."""
+    L = lib()
+    L.p2e_schedule_wiring.restype = C.c_long
+    n = L.p2e_schedule_wiring(C.c_int(program), None, C.c_size_t(0))
+    arr = (_GenWiring * n)()
+    L.p2e_schedule_wiring(C.c_int(program), arr, C.c_size_t(n))
+    return [([(int(w.src[k]), int(w.num_limbs[k])) for k in range(w.num_operands)], bool(w.range_check)) for w in arr]
+
+
+def wiring_const(const_id: int):
+    """(value, num_limbs) of circuit constant `const_id` (SRC_CONST | const_id in schedule_wiring)."""
+    buf = (C.c_uint8 * 32)()
+    nl = lib().p2e_wiring_const(C.c_uint32(const_id), buf)
+    if nl < 0:
+        raise P2EError("unknown constant id")
+    return int.from_bytes(bytes(buf), "little"), int(nl)
 
 
 def schedule_num_cols(program: int = PROGRAM_VERIFY) -> int:

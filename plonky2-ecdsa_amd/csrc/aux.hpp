@@ -20,8 +20,14 @@ namespace p2e {
 
 // where the limbs of a target live
 constexpr u32 AUX_SRC_NONE = 0xFFFFFFFFu;
-constexpr u32 AUX_SRC_CONST = 0x80000000u;     // | 2 * constant point id + (0: x, 1: y)
-constexpr u32 AUX_SRC_INPUT_PY = 0x40000000u;  // the caller's pk.y (packed 32-byte input)
+constexpr u32 AUX_SRC_CONST = 0x80000000u;     // | constant id: 2 * constant point id + (0: x, 1: y), or a CONSTV_* scalar constant
+constexpr u32 AUX_SRC_INPUT = 0x40000000u;     // | INPUT_*: a caller's packed 32-byte input (a 9-limb virtual target)
+constexpr u32 AUX_SRC_INPUT_PY = 0x40000000u;  // the caller's pk.y
+constexpr u32 AUX_SRC_AUX = 0x20000000u;       // | column of the built-in-generator (aux) matrix
+constexpr u32 AUX_SRC_KIND_MASK = 0xE0000000u;
+constexpr u32 INPUT_PY = 0, INPUT_PX = 1, INPUT_MSG = 2, INPUT_R = 3, INPUT_S = 4;   // Buffers / p2e.h argument slots
+// scalar constants the gadgets create (constant_nonnative): zero has NO limbs (Q5), B = 7 one
+constexpr u32 CONSTV_ZERO = 6, CONSTV_B7 = 7, CONSTV_GLV_S = 8, CONSTV_GLV_BETA = 9, NUM_CONSTV = 10;
 // columns of the result limbs inside the column block of one curve op (gadgets/curve.rs:160-243 emission order)
 constexpr u32 COL_ADD_X3 = 150, COL_ADD_Y3 = 221, COL_DBL_X3 = 201, COL_DBL_Y3 = 272, COL_CADD_X = 231, COL_CADD_Y = 241;
 

@@ -14,6 +14,7 @@
 #include "consts.hpp"
 #include "pipeline.hpp"
 #include "prims.hpp"
+#include "quad.hpp"
 #include "schedule.hpp"
 
 using namespace p2e;
@@ -55,6 +56,19 @@ __global__ __launch_bounds__(BS) void k_chains(Program G, Buffers B, int lo, int
     __builtin_amdgcn_s_setprio(3);
     size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
     if (i < B.n) body_chain_range(G, B, i, lo, hi, table_affine != 0, continue_prefix != 0);
+}
+// small batches: four lanes per signature (quad.hpp); the four lanes of a quad are consecutive threads
+__global__ __launch_bounds__(BS) void k_chains_quad(Program G, Buffers B, int lo, int hi, int table_affine, int continue_prefix) {
+    __builtin_amdgcn_s_setprio(3);
+    const size_t g = (size_t)blockIdx.x * BS + threadIdx.x;
+    const size_t i = g >> 2;
+    if (i < B.n) body_chain_range_quad(G, B, i, (int)(g & 3), lo, hi, table_affine != 0, continue_prefix != 0);
+}
+// one inversion batch cut into 2^split_log2 sub-ranges, one lane each
+__global__ __launch_bounds__(BS) void k_batch_inv_split(Program G, Buffers B, int lo, int hi, int have_prefix, int split_log2) {
+    const size_t g = (size_t)blockIdx.x * BS + threadIdx.x;
+    const size_t i = g >> split_log2;
+    if (i < B.n) body_batch_inv_split(G, B, i, lo, hi, have_prefix != 0, (int)(g & ((1u << split_log2) - 1)), 1 << split_log2);
 }
 // independent interleaved sub-chains of a piece, one per blockIdx.y (the MSM window table)
 __global__ __launch_bounds__(BS) void k_chain_rows(Program G, Buffers B, int lo, int count) {
@@ -373,7 +387,9 @@ struct p2e_ctx {
     // caller's stream underneath the following pieces.
     static constexpr int MAX_PIECES = 16;
     static constexpr int MAX_SEG = 2 * MAX_PIECES + 2;
-    hipStream_t st_msm = nullptr, st_fixed = nullptr;
+    // st_binv, st_c2: second phase-B and second phase-C stream of the small-batch plan
+    hipStream_t st_msm = nullptr, st_fixed = nullptr, st_binv = nullptr, st_c2 = nullptr;
+    hipEvent_t ev_c2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_fixed = nullptr, ev_piece[MAX_SEG] = {}, ev_binv[MAX_SEG] = {};
     // one event pair around every expansion launch; kind 0 = k_expand (op by op), 1 = k_expand_runs
     static constexpr int MAX_EXPAND = 2 * MAX_SEG;
@@ -382,10 +398,15 @@ struct p2e_ctx {
     double expand_cols[MAX_EXPAND] = {};
     int expand_kind[MAX_EXPAND] = {};
     int msm_pieces = 8, fixed_pieces = 2;   // one Montgomery inversion batch per piece
+    int msm_pieces_small = 5, fixed_pieces_small = 1;   // ... of the small-batch plan (fewer launches and inversions)
     int run_iters = 9;                      // MSM-loop iterations per expansion run (0: expand op by op)
     // A run is walked by ONE lane, so a launch of r runs has only r * n/64 waves: below this batch size the
     // 1024 SIMDs are better filled by one workgroup row per op (2^10 glv_mul fills: 3.0 ms against 9.5 ms)
     size_t runs_min_n = 49152;
+    // Below this batch size phases A and B are latency, not throughput: four lanes per signature walk the chains
+    // (k_chains_quad) and every inversion batch is cut into 2^binv_split_log2 sub-ranges (k_batch_inv_split)
+    size_t quad_max_n = 24576;
+    int binv_split_log2 = 2;
     Aff* d_cpts = nullptr;
     Aff* d_fbtab = nullptr;
     DeviceProgram progs[2];
@@ -445,7 +466,7 @@ static std::vector<OpDesc> host_ops(int program, int run_iters) {
 }
 
 struct ScratchLayout {
-    size_t px, py, pz, pw, pref, ax, ay, dig4, dig2, dyn, src, err32, valid8, total;
+    size_t px, py, pz, pw, pref, ax, ay, dig4, dig2, msrc, dyn, src, err32, valid8, total;
 };
 static ScratchLayout scratch_layout(const Program& G, size_t n) {
     ScratchLayout L{};
@@ -464,6 +485,7 @@ static ScratchLayout scratch_layout(const Program& G, size_t n) {
     L.ay = take((size_t)G.num_slots * n * 32);
     L.dig4 = take((size_t)FB_WINDOWS * n);
     L.dig2 = take((size_t)MSM_DIGITS * n);
+    L.msrc = take((size_t)MSM_DIGITS * n * 2);
     L.dyn = take((size_t)G.num_cadd * n * 2);
     L.src = take((size_t)G.num_ops * 2 * n * 2);
     L.err32 = take(n * 4);
@@ -520,6 +542,11 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         if (v >= 0 && v <= MSM_DIGITS) c->run_iters = v;
     }
     if (const char* env = getenv("P2E_RUNS_MIN_N")) c->runs_min_n = (size_t)strtoull(env, nullptr, 10);
+    if (const char* env = getenv("P2E_QUAD_MAX_N")) c->quad_max_n = (size_t)strtoull(env, nullptr, 10);
+    if (const char* env = getenv("P2E_BINV_SPLIT_LOG2")) {
+        int v = atoi(env);
+        if (v >= 0 && v <= 4) c->binv_split_log2 = v;
+    }
     for (int p = 0; p < 2; p++) {
         c->progs[p].prog = host_program(p).prog;
         std::vector<OpDesc> ops = host_ops(p, c->run_iters);
@@ -550,6 +577,9 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     HIP_TRY(hipStreamCreateWithPriority(&c->st_msm, hipStreamNonBlocking, prio_hi));
     HIP_TRY(hipStreamCreateWithPriority(&c->st_fixed, hipStreamNonBlocking, prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->st_binv, hipStreamNonBlocking, prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->st_c2, hipStreamNonBlocking, prio_lo));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_c2, hipEventDisableTiming));
     for (auto& e : c->ev_binv) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fixed, hipEventDisableTiming));
@@ -563,6 +593,14 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     if (const char* env = getenv("P2E_FIXED_PIECES")) {
         int v = atoi(env);
         if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->fixed_pieces = v;
+    }
+    if (const char* env = getenv("P2E_MSM_PIECES_SMALL")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->msm_pieces_small = v;
+    }
+    if (const char* env = getenv("P2E_FIXED_PIECES_SMALL")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->fixed_pieces_small = v;
     }
     cleanup.c = nullptr;
     *out = c;
@@ -590,12 +628,12 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_binv)
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t st : {c->st_msm, c->st_fixed})
+    for (hipStream_t st : {c->st_msm, c->st_fixed, c->st_binv, c->st_c2})
         if (st) {
             (void)hipStreamSynchronize(st);
             (void)hipStreamDestroy(st);
         }
-    for (hipEvent_t e : {c->ev_fork, c->ev_fixed})
+    for (hipEvent_t e : {c->ev_fork, c->ev_fixed, c->ev_c2})
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_piece)
         if (e) (void)hipEventDestroy(e);
@@ -750,7 +788,7 @@ struct Staged {
     // it may still be running when the staged buffers are freed or the scratch is reused by the next call.
     void release(bool failed) {
         if (failed) {
-            for (hipStream_t st : {c->st_msm, c->st_fixed})
+            for (hipStream_t st : {c->st_msm, c->st_fixed, c->st_binv, c->st_c2})
                 if (st) (void)hipStreamSynchronize(st);
             (void)hipStreamSynchronize(c->stream);
             (void)hipGetLastError();
@@ -997,6 +1035,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     B.AY = (U256*)(base + L.ay);
     B.dig4 = (uint8_t*)(base + L.dig4);
     B.dig2 = (uint8_t*)(base + L.dig2);
+    B.msrc = (uint16_t*)(base + L.msrc);
     B.dyn = (uint16_t*)(base + L.dyn);
     B.src = (uint16_t*)(base + L.src);
     B.cpts = c->d_cpts;
@@ -1058,6 +1097,10 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     Seg segs[p2e_ctx::MAX_SEG];
     int ns = 0;
     const bool verify = G.num_chains == 3;
+    // small batches: four lanes per signature in phase A, split inversion batches in phase B (quad.hpp)
+    const bool quad = n <= c->quad_max_n;
+    const int msm_pieces = quad ? c->msm_pieces_small : c->msm_pieces;
+    const int fixed_pieces = quad ? c->fixed_pieces_small : c->fixed_pieces;
     auto cut = [&](int lo, int hi, int pieces, hipStream_t st) {
         if (pieces > hi - lo) pieces = hi - lo;
         int a = lo;
@@ -1068,7 +1111,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             a += len;
         }
     };
-    if (verify) cut(G.chain_begin[1], G.chain_end[1], c->fixed_pieces, c->st_fixed);
+    if (verify) cut(G.chain_begin[1], G.chain_end[1], fixed_pieces, c->st_fixed);
     const int first_msm = ns;
     {
         // MSM chain = window table (its own piece: inverted first, read in affine form by everything after) +
@@ -1077,7 +1120,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         const int lb = G.msm_loop_begin, iters = G.msm_loop_iters, le = lb + 3 * iters;
         const int R = run_iters > 0 ? run_iters : 1;
         const int nruns = (iters + R - 1) / R;
-        int groups = c->msm_pieces > 1 ? c->msm_pieces - 1 : 1;
+        int groups = msm_pieces > 1 ? msm_pieces - 1 : 1;
         if (groups > nruns) groups = nruns;
         segs[ns++] = Seg{lo0, lb, lb - lo0, c->st_msm, false, lo0, lb, 0, 0};
         int run = 0;
@@ -1103,6 +1146,14 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     if (verify) segs[ns - 1].final_after = true;
     c->n_seg = ns;
 
+    const unsigned gx4 = (unsigned)((4 * n + BS - 1) / BS);
+    auto launch_binv = [&](hipStream_t st, int lo, int hi, int have_prefix) {
+        if (quad && c->binv_split_log2 > 0)
+            hipLaunchKernelGGL(k_batch_inv_split, dim3((unsigned)(((n << c->binv_split_log2) + BS - 1) / BS)), dim3(BS), 0, st, G, B,
+                               lo, hi, have_prefix, c->binv_split_log2);
+        else
+            hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, st, G, B, lo, hi, have_prefix);
+    };
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (gx_wide) LAUNCH_EMIT(k_scalar, true, dim3(gx_wide), c->stream, G, B, (size_t)0);
     if (gx_tail) LAUNCH_EMIT(k_scalar, false, dim3(gx_tail), c->stream, G, B, n_wide);
@@ -1110,19 +1161,25 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->st_msm, c->ev_fork, 0));
     HIP_TRY(hipStreamWaitEvent(c->st_fixed, c->ev_fork, 0));
+    if (quad) HIP_TRY(hipStreamWaitEvent(c->st_binv, c->ev_fork, 0));
     // chains
     for (int k = 0; k < ns; k++) {
         Seg& sg = segs[k];
         // once the table piece has been inverted on this stream (below), later pieces read the table affine
-        const int table_affine = (sg.chain_stream == c->st_msm && k > first_msm) ? 1 : 0;
+        // (small-batch plan: the FIRST loop piece does not wait for the table's inversion -- it reads the table in
+        // Jacobian form, one level more per addition, and starts ~0.15 ms earlier; the table's phase B runs beside it)
+        const int table_affine = (sg.chain_stream == c->st_msm && k > first_msm + (quad ? 1 : 0)) ? 1 : 0;
+        if (quad && k == first_msm + 2) HIP_TRY(hipStreamWaitEvent(c->st_msm, c->ev_binv[first_msm], 0));
         // glv_mul alone: the window table as 2 chains of 4 adds, then 6 and 9 independent adds (body_chain_rows):
         // -6 % at 2^10, -4 % at 2^16.  Not in the verify program: there the fixed-base chain runs beside it, three
         // 186-VGPR waves do not fit a SIMD and the rows only queue (+0.6...1 % measured).
-        const bool table_rows = !verify && k == first_msm && sg.hi - sg.lo == MSM_TABLE_OPS;
+        const bool table_rows = (!verify || quad) && k == first_msm && sg.hi - sg.lo == MSM_TABLE_OPS;
         if (table_rows) {
             hipLaunchKernelGGL(k_chain_rows, dim3(gx, 2), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, 4);
             hipLaunchKernelGGL(k_chain_rows, dim3(gx, 6), dim3(BS), 0, sg.chain_stream, G, B, sg.lo + 8, 1);
             hipLaunchKernelGGL(k_chain_rows, dim3(gx, 9), dim3(BS), 0, sg.chain_stream, G, B, sg.lo + 14, 1);
+        } else if (quad) {
+            hipLaunchKernelGGL(k_chains_quad, dim3(gx4), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, sg.hi, table_affine, 0);
         } else {
             hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, sg.chain_stream, G, B, sg.lo, sg.hi, table_affine, 0);
         }
@@ -1130,7 +1187,10 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         if (sg.final_after) {
             HIP_TRY(hipStreamWaitEvent(c->st_msm, c->ev_fixed, 0));
             // the final add joins the inversion batch of the last MSM piece
-            hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, c->st_msm, G, B, G.chain_begin[2], G.chain_end[2], 0, 1);
+            if (quad)
+                hipLaunchKernelGGL(k_chains_quad, dim3(gx4), dim3(BS), 0, c->st_msm, G, B, G.chain_begin[2], G.chain_end[2], 0, 1);
+            else
+                hipLaunchKernelGGL(k_chains, dim3(gx), dim3(BS), 0, c->st_msm, G, B, G.chain_begin[2], G.chain_end[2], 0, 1);
             sg.hi = G.chain_end[2];
             sg.s_hi = G.chain_end[2];
         }
@@ -1140,8 +1200,10 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             // stream (the rest of the chain is not on the critical path: it ends long before the expansion
             // does), so that the first k_expand can start ~0.8 ms earlier than if it queued behind the
             // fixed-base chain on the other stream.
-            hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, c->st_msm, G, B, sg.lo, sg.hi, table_rows ? 0 : 1);
-            HIP_TRY(hipEventRecord(c->ev_binv[k], c->st_msm));
+            hipStream_t st_tab = quad ? c->st_binv : c->st_msm;
+            if (quad) HIP_TRY(hipStreamWaitEvent(st_tab, c->ev_piece[k], 0));
+            launch_binv(st_tab, sg.lo, sg.hi, table_rows ? 0 : 1);
+            HIP_TRY(hipEventRecord(c->ev_binv[k], st_tab));
         }
     }
     // order of phases B / C: by readiness
@@ -1154,19 +1216,31 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             order[b - 1] = t;
         }
     c->n_expand = 0;
+    bool used_c2 = false;
     for (int q = 0; q < ns; q++) {
         const int k = order[q];
         const Seg& sg = segs[k];
         // HIP multiplexes streams onto a few hardware queues (4 by default) and kernels of one queue run
         // in order: a dedicated inversion stream ended up sharing the caller's queue and serialised B
         // with C.  The fixed-base chain's stream is idle after its first ~1 ms, so phase B lives there.
-        hipStream_t st_b = c->st_fixed;
+        // (small-batch plan: phase B of consecutive pieces alternates between two streams, so that an inversion batch
+        // does not queue behind the previous one -- there the chains are no slower than phase B)
+        hipStream_t st_b = (quad && (q & 1)) ? c->st_binv : c->st_fixed;
         if (k != first_msm) {
             HIP_TRY(hipStreamWaitEvent(st_b, c->ev_piece[k], 0));
-            hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, st_b, G, B, sg.lo, sg.hi, 1);
+            launch_binv(st_b, sg.lo, sg.hi, 1);
             HIP_TRY(hipEventRecord(c->ev_binv[k], st_b));
         }
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_binv[k], 0));
+        // (small-batch plan: phase C alternates between the caller's stream and a second one, so that an expansion
+        // waiting for its inversion batch does not hold up the expansions queued behind it)
+        hipStream_t st_c = (quad && (q & 1)) ? c->st_c2 : c->stream;
+        used_c2 = used_c2 || st_c == c->st_c2;
+        HIP_TRY(hipStreamWaitEvent(st_c, c->ev_binv[k], 0));
+        // an expansion also reads affine results of EARLIER pieces (the first operand of its first op, the window
+        // table, the fixed-base result under the final add): with one expansion stream the queue order implied
+        // their inversion batches, with two it has to be said
+        if (quad)
+            for (int q2 = 0; q2 < q; q2++) HIP_TRY(hipStreamWaitEvent(st_c, c->ev_binv[order[q2]], 0));
         auto cols_of = [&](int lo, int hi) {
             double cw = 0;
             for (int t = lo; t < hi; t++)
@@ -1177,22 +1251,26 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             const int R = run_iters;
             const unsigned nr = (unsigned)((sg.it1 - sg.it0 + R - 1) / R);
             const int e = c->n_expand++;
-            HIP_TRY(hipEventRecord(c->ev_c0[e], c->stream));
-            if (gx_wide) LAUNCH_EMIT(k_expand_runs, true, dim3(gx_wide, nr), c->stream, G, B, sg.it0, R, sg.it1, (size_t)0);
-            if (gx_tail) LAUNCH_EMIT(k_expand_runs, false, dim3(gx_tail, nr), c->stream, G, B, sg.it0, R, sg.it1, n_wide);
-            HIP_TRY(hipEventRecord(c->ev_c1[e], c->stream));
+            HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
+            if (gx_wide) LAUNCH_EMIT(k_expand_runs, true, dim3(gx_wide, nr), st_c, G, B, sg.it0, R, sg.it1, (size_t)0);
+            if (gx_tail) LAUNCH_EMIT(k_expand_runs, false, dim3(gx_tail, nr), st_c, G, B, sg.it0, R, sg.it1, n_wide);
+            HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 1;
             c->expand_cols[e] = cols_of(G.msm_loop_begin + 3 * sg.it0, G.msm_loop_begin + 3 * sg.it1);
         }
         if (sg.s_hi > sg.s_lo) {
             const int e = c->n_expand++;
-            HIP_TRY(hipEventRecord(c->ev_c0[e], c->stream));
-            if (gx_wide) LAUNCH_EMIT(k_expand, true, dim3(gx_wide, (unsigned)(sg.s_hi - sg.s_lo)), c->stream, G, B, sg.s_lo, (size_t)0);
-            if (gx_tail) LAUNCH_EMIT(k_expand, false, dim3(gx_tail, (unsigned)(sg.s_hi - sg.s_lo)), c->stream, G, B, sg.s_lo, n_wide);
-            HIP_TRY(hipEventRecord(c->ev_c1[e], c->stream));
+            HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
+            if (gx_wide) LAUNCH_EMIT(k_expand, true, dim3(gx_wide, (unsigned)(sg.s_hi - sg.s_lo)), st_c, G, B, sg.s_lo, (size_t)0);
+            if (gx_tail) LAUNCH_EMIT(k_expand, false, dim3(gx_tail, (unsigned)(sg.s_hi - sg.s_lo)), st_c, G, B, sg.s_lo, n_wide);
+            HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 0;
             c->expand_cols[e] = cols_of(sg.s_lo, sg.s_hi);
         }
+    }
+    if (used_c2) {   // join the second expansion stream
+        HIP_TRY(hipEventRecord(c->ev_c2, c->st_c2));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_c2, 0));
     }
     HIP_TRY(hipEventRecord(c->ev[5], c->stream));
     hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, B.err, B.valid, err, valid, n, c->d_counter);
@@ -1400,6 +1478,29 @@ extern "C" long p2e_schedule_describe(int program, p2e_gen_desc* out, size_t cap
         std::strncpy(out[i].label, g[i].label.c_str(), sizeof(out[i].label) - 1);
     }
     return (long)g.size();
+}
+extern "C" long p2e_schedule_wiring(int program, p2e_gen_wiring* out, size_t cap) {
+    if (program < 0 || program > 1) return P2E_E_INVALID;
+    const auto& g = host_program(program).gens;
+    for (size_t i = 0; i < g.size() && i < cap && out; i++) {
+        out[i].num_operands = g[i].nops;
+        out[i].range_check = g[i].range_check ? 1 : 0;
+        for (int k = 0; k < 4; k++) {
+            out[i].src[k] = g[i].src[k];
+            out[i].num_limbs[k] = g[i].nl[k];
+        }
+    }
+    return (long)g.size();
+}
+extern "C" int p2e_wiring_const(uint32_t id, uint8_t out32[32]) {
+    if (id >= NUM_CONSTV || !out32) return P2E_E_INVALID;
+    const U256 v = host::ScheduleBuilder::const_value(id);
+    std::memcpy(out32, v.w, 32);
+    u32 l[NL];
+    split29(v, l);
+    int n = NL;
+    while (n > 0 && l[n - 1] == 0) n--;
+    return n;
 }
 extern "C" long p2e_schedule_num_cols(int program) {
     if (program < 0 || program > 1) return P2E_E_INVALID;

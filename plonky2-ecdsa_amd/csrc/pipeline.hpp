@@ -37,6 +37,33 @@ struct OpDesc {
     u32 ref1, ref2;     // operands
     u32 col;            // first output column
 };
+static_assert(sizeof(OpDesc) == 16, "load_op reads a descriptor as one 16-byte word");
+// One descriptor of the op table.  The table is written once at context creation and never while a kernel runs:
+// on the device it is read through the CONSTANT address space, which lets a wave-uniform index become one
+// s_load_dwordx4 -- through the plain pointer the compiler cannot rule out that the kernel's own scratch stores alias
+// the table and reads every field with a separate vector load behind the stores (vmcnt is in-order on gfx9, so
+// each op then waited for the previous op's stores to drain).
+P2E_HD OpDesc load_op(const OpDesc* ops, int t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(4))) * cptr;
+    const u32x4 v = ((cptr)(uintptr_t)ops)[__builtin_amdgcn_readfirstlane(t)];   // every caller's t is wave-uniform
+    u32 x = v.x, y = v.y, z = v.z, w = v.w;
+    // keep it ONE scalar 16-byte load: without this the compiler narrows the access to the bytes a caller uses, and a
+    // sub-dword load cannot be scalar on gfx9 -- it becomes a vector load whose wait drains everything in flight
+    asm volatile("" : "+s"(x), "+s"(y), "+s"(z), "+s"(w));
+    OpDesc d;
+    d.kind = (uint8_t)(x & 0xFFu);
+    d.flags = (uint8_t)((x >> 8) & 0xFFu);
+    d.cadd_idx = (uint16_t)(x >> 16);
+    d.ref1 = y;
+    d.ref2 = z;
+    d.col = w;
+    return d;
+#else
+    return ops[t];
+#endif
+}
 constexpr int CONST_RANDO = 0, CONST_NEG_RANDO = 1, CONST_NEG_RANDO_146 = 2, NUM_CONST_PTS = 3;
 constexpr int FB_WINDOWS = 66, MSM_DIGITS = 73;
 constexpr int MSM_TABLE_OPS = 23;  // curve_msm_circuit's precomputation: 8 + 6 + 9 adds (gadgets/curve_msm.rs:45-60)
@@ -80,6 +107,7 @@ struct Buffers {
     U256 *PX, *PY, *PZ, *PW, *PREF, *AX, *AY;
     uint8_t* dig4;   // [66][n]
     uint8_t* dig2;   // [73][n]   4*m_d + n_d
+    uint16_t* msrc;  // [73][n]   resolved source id of precomputation[4*m_d + n_d] (slot, or constant | DYN_CONST_BIT)
     uint16_t* dyn;   // [num_cadd][n]
     uint16_t* src;   // [2 * num_ops][n]: resolved operand ids of every op (written by phase A for phase C)
     // constants
@@ -172,8 +200,13 @@ P2E_HD void body_scalar(const Program& G, const Buffers& B, size_t i) {
         ok = ok && u256_eq(sb, k);
         e.flush();
     }
-    for (int d = 0; d < MSM_DIGITS; d++)
-        B.dig2[(size_t)d * B.n + i] = (uint8_t)(4 * digit_of<2>(g.k2, d) + digit_of<2>(g.k1, d));
+    for (int d = 0; d < MSM_DIGITS; d++) {
+        const u32 idx = 4 * digit_of<2>(g.k2, d) + digit_of<2>(g.k1, d);
+        B.dig2[(size_t)d * B.n + i] = (uint8_t)idx;
+        // the table entry's source id, resolved here once: phases A would otherwise chain digit -> msm_tab -> point loads
+        const u32 tr = G.msm_tab[idx];
+        B.msrc[(size_t)d * B.n + i] = ref_kind(tr) == R_CONST ? (uint16_t)(ref_id(tr) | DYN_CONST_BIT) : (uint16_t)ref_id(tr);
+    }
     // glv_mul gadgets/glv.rs:87-104
     U256 beta;
     {
@@ -215,10 +248,7 @@ P2E_HD uint16_t resolve_src(const Program& G, const Buffers& B, size_t i, u32 re
     if (k == R_SLOT) return (uint16_t)id;
     if (k == R_CONST) return (uint16_t)(id | DYN_CONST_BIT);
     if (k == R_DYN) return B.dyn[(size_t)id * B.n + i];
-    if (k == R_MSMTAB) {
-        u32 t = G.msm_tab[B.dig2[(size_t)id * B.n + i]];
-        return ref_kind(t) == R_CONST ? (uint16_t)(ref_id(t) | DYN_CONST_BIT) : (uint16_t)ref_id(t);
-    }
+    if (k == R_MSMTAB) return B.msrc[(size_t)id * B.n + i];
     return 0;  // R_FBTAB never goes through here
 }
 P2E_HD Aff load_aff_src(const Buffers& B, size_t i, uint16_t src) {
@@ -272,7 +302,7 @@ P2E_HD Jac jac_select3(bool c1, const Jac& a, bool c2, const Jac& b, const Jac& 
 // the loop pieces start), so table operands are read in affine form and the 73 window additions are
 // mixed additions (11 multiplications instead of 17).
 P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, bool table_affine, ChainState& st) {
-    const OpDesc op = B.ops[t];
+    const OpDesc op = load_op(B.ops, t);
     size_t o = (size_t)t * B.n + i;
     JacW res;
     uint16_t src1 = resolve_src(G, B, i, op.ref1);
@@ -381,7 +411,9 @@ P2E_HD void body_verify_check(const Program& G, const Buffers& B, size_t i) {
 // Reads the Jacobian results (left intact: later pieces of the chain still consume them), writes the
 // affine points to AX/AY and v^-1 over W.  have_prefix: [t0, t1) is exactly one inversion batch of phase A,
 // whose prefix products are already in PREF (the normal case); otherwise the forward pass runs here.
-P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0, int t1, bool have_prefix) {
+// uniform_t: every lane of the wave walks the same ops (so the descriptor can be a scalar load); false when lanes own
+// different sub-ranges (body_batch_inv_split)
+P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0, int t1, bool have_prefix, bool uniform_t = true) {
     (void)G;
     U256 acc;
     if (have_prefix) {
@@ -404,7 +436,8 @@ P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0,
         U256 zi = fp_mul(inv, B.PREF[o]);
         inv = fp_mul(inv, z);
         B.PW[o] = fp_mul(B.PW[o], zi);  // v^-1 of op t
-        if (!(B.ops[t].flags & F_NO_AFFINE)) {
+        const uint8_t flags = uniform_t ? load_op(B.ops, t).flags : B.ops[t].flags;
+        if (!(flags & F_NO_AFFINE)) {
             U256 zi2 = fp_sqr(zi);
             U256 zi3 = fp_mul(zi2, zi);
             B.AX[o] = fp_mul(B.PX[o], zi2);
@@ -450,7 +483,7 @@ P2E_HD Aff wit_curve_double(E& e, const Aff& p, const U256& vinv, uint8_t& err) 
 }
 template <class E>
 P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t) {
-    const OpDesc op = B.ops[t];
+    const OpDesc op = load_op(B.ops, t);
     uint8_t err = 0;
     E e = E::at(B.sink, i, op.col);
     // operands were resolved by phase A: one level of index loads, then the points
@@ -493,7 +526,7 @@ P2E_HD void body_expand_run(const Program& G, const Buffers& B, size_t i, int it
 #pragma unroll 1
 #endif
         for (int k = 0; k < 2; k++) {  // curve_repeated_double(result, 2)
-            E e = E::at(B.sink, i, B.ops[t + k].col);
+            E e = E::at(B.sink, i, load_op(B.ops, t + k).col);
             p = wit_curve_double(e, p, B.PW[(size_t)(t + k) * B.n + i], err);
             e.flush();
         }
@@ -501,7 +534,7 @@ P2E_HD void body_expand_run(const Program& G, const Buffers& B, size_t i, int it
         const uint16_t s2 = B.src[(size_t)(2 * tc + 1) * B.n + i];
         Aff p2 = load_aff_src(B, i, (uint16_t)(s2 & (DYN_CONST_BIT | SRC_ID_MASK)));
         const bool b = (s2 & SRC_SEL_BIT) != 0;
-        E e = E::at(B.sink, i, B.ops[tc].col);
+        E e = E::at(B.sink, i, load_op(B.ops, tc).col);
         Aff sm = wit_curve_add(e, p, p2, B.PW[(size_t)tc * B.n + i], err);
         const U256 z = u256_zero();
         Aff nx;

@@ -29,10 +29,18 @@ namespace host {
 enum GenKind : int { GEN_ADD = 0, GEN_SUB = 1, GEN_ADD_MANY = 2, GEN_MUL = 3, GEN_INV = 4, GEN_GLV = 5 };
 enum Field : int { FIELD_BASE = 0, FIELD_SCALAR = 1 };
 
+// One hot-path generator: its output columns AND where its operands live (the wiring the reference's gadgets fix when
+// they pass targets from one call to the next).  src[k] is a source code of aux.hpp (a witness column, an aux
+// column, a caller input, a constant), nl[k] the limbs that operand target really has.  range_check: the gadget's
+// range_check flag (an extra cmp_biguint in the constraint block, gadgets/nonnative.rs:180-190).
 struct GenOp {
     int kind, field;
     u32 col, ncols;
     std::string label;
+    int nops = 0;
+    u32 src[4] = {AUX_SRC_NONE, AUX_SRC_NONE, AUX_SRC_NONE, AUX_SRC_NONE};
+    uint8_t nl[4] = {0, 0, 0, 0};
+    bool range_check = false;
 };
 
 // symbolic NonNativeTarget: the hot path never needs its value on the host, only its identity and, for the
@@ -70,35 +78,42 @@ public:
     AuxTables aux_tab{};
 
     // ---- CircuitBuilderNonNative ----  (every result target = the first 9 columns its generator writes)
-    NonNativeTarget add_nonnative(NonNativeTarget a, NonNativeTarget, bool /*range_check*/ = false) {
-        return {a.field, gen(GEN_ADD, a.field, 10), NL};
+    NonNativeTarget add_nonnative(NonNativeTarget a, NonNativeTarget b, bool range_check = false) {
+        return {a.field, gen(GEN_ADD, a.field, 10, {a, b}, range_check), NL};
     }
-    NonNativeTarget sub_nonnative(NonNativeTarget a, NonNativeTarget, bool = false) {
-        return {a.field, gen(GEN_SUB, a.field, 10), NL};
+    NonNativeTarget sub_nonnative(NonNativeTarget a, NonNativeTarget b, bool range_check = false) {
+        return {a.field, gen(GEN_SUB, a.field, 10, {a, b}, range_check), NL};
     }
-    NonNativeTarget add_many_nonnative(const std::vector<NonNativeTarget>& xs, bool = false) {
+    NonNativeTarget add_many_nonnative(const std::vector<NonNativeTarget>& xs, bool range_check = false) {
         if (xs.size() == 1) return xs[0];
-        return {xs[0].field, gen(GEN_ADD_MANY, xs[0].field, 10), NL};
+        return {xs[0].field, gen(GEN_ADD_MANY, xs[0].field, 10, xs, range_check), NL};
     }
-    NonNativeTarget mul_nonnative(NonNativeTarget a, NonNativeTarget, bool = false) {
+    NonNativeTarget mul_nonnative(NonNativeTarget a, NonNativeTarget b, bool range_check = false) {
         // MulNonnativeGate r,q,check_sum (35) + CheckSumGate b (16); the product target = the r wires
-        return {a.field, gen(GEN_MUL, a.field, 51), NL};
+        return {a.field, gen(GEN_MUL, a.field, 51, {a, b}, range_check), NL};
     }
-    NonNativeTarget inv_nonnative(NonNativeTarget a, bool = false) {
-        return {a.field, gen(GEN_INV, a.field, 18), NL};
+    NonNativeTarget inv_nonnative(NonNativeTarget a, bool range_check = false) {
+        return {a.field, gen(GEN_INV, a.field, 18, {a}, range_check), NL};
     }
-    NonNativeTarget neg_nonnative(NonNativeTarget a, bool = false) { return sub_nonnative(a, a); }
+    NonNativeTarget constant_nonnative(int field, u32 const_id) {   // constant_biguint: convert_base's limb count (Q5)
+        return {field, AUX_SRC_CONST | const_id, const_num_limbs(const_value(const_id))};
+    }
+    NonNativeTarget neg_nonnative(NonNativeTarget a, bool range_check = false) {   // gadgets/nonnative.rs:491-500
+        return sub_nonnative(constant_nonnative(a.field, CONSTV_ZERO), a, range_check);
+    }
     // gadgets/nonnative.rs:584-596: not(b), neg, neg * b, x * not_b, add
-    NonNativeTarget nonnative_conditional_neg(NonNativeTarget x, BoolTarget b, bool = false) {
+    NonNativeTarget nonnative_conditional_neg(NonNativeTarget x, BoolTarget b, bool range_check = false) {
         AuxItem it{};
         it.kind = AUX_CNEG;
         it.a = b.col;
+        const u32 base = aux_col_;   // [not_b, neg * b (9), x * not_b (x.nl)]
         NonNativeTarget neg = neg_nonnative(x);
         it.sumx = neg.col;
         it.p1x = x.col;
         it.nlx = (uint8_t)x.nl;
         aux(it, 1 + NL + (u32)x.nl);
-        return add_nonnative(neg, x);
+        NonNativeTarget t{x.field, AUX_SRC_AUX | (base + 1), NL}, f{x.field, AUX_SRC_AUX | (base + 1 + NL), x.nl};
+        return add_nonnative(t, f, range_check);
     }
     // gadgets/split_nonnative.rs:25-50 / :52-72: split_le_base bits of every limb, then the digits built from them
     void split_nonnative_to_4_bit_limbs(NonNativeTarget v) {
@@ -121,32 +136,35 @@ public:
     }
 
     // ---- CircuitBuilderCurve ----
-    void curve_assert_valid() {
+    void curve_assert_valid(const AffinePointTarget& p) {   // gadgets/curve.rs:123-135
         Scope s(this, "assert_valid");
-        NonNativeTarget f{FIELD_BASE};
-        mul_nonnative(f, f, true);
-        mul_nonnative(f, f);
-        mul_nonnative(f, f);
-        mul_nonnative(f, f);
-        add_nonnative(f, f);
-        add_nonnative(f, f, true);
+        const NonNativeTarget x = x_of(p), y = y_of(p);
+        const NonNativeTarget a = constant_nonnative(FIELD_BASE, CONSTV_ZERO), b = constant_nonnative(FIELD_BASE, CONSTV_B7);
+        mul_nonnative(y, y, true);
+        NonNativeTarget x2 = mul_nonnative(x, x);
+        NonNativeTarget x3 = mul_nonnative(x2, x);
+        NonNativeTarget ax = mul_nonnative(a, x);
+        NonNativeTarget axb = add_nonnative(ax, b);
+        add_nonnative(x3, axb, true);
     }
-    AffinePointTarget curve_add(AffinePointTarget p1, AffinePointTarget p2, bool = false) {
-        return curve_op(OP_ADD, p1, p2);
+    AffinePointTarget curve_add(AffinePointTarget p1, AffinePointTarget p2, bool range_check = false) {
+        return curve_op(OP_ADD, p1, p2, range_check);
     }
-    AffinePointTarget curve_double(AffinePointTarget p, bool = false) { return curve_op(OP_DBL, p, p); }
-    AffinePointTarget curve_repeated_double(AffinePointTarget p, int n, bool = false) {
-        for (int i = 0; i < n; i++) p = curve_double(p);
-        return p;
+    AffinePointTarget curve_double(AffinePointTarget p, bool range_check = false) { return curve_op(OP_DBL, p, p, range_check); }
+    AffinePointTarget curve_repeated_double(AffinePointTarget p, int n, bool range_check = false) {   // gadgets/curve.rs:187-200
+        for (int i = 0; i < n - 1; i++) p = curve_double(p, false);
+        return curve_double(p, range_check);
     }
-    // b is always "random-access index != 0" on the supported circuits; it is derived from p2's ref
-    AffinePointTarget curve_conditional_add(AffinePointTarget p1, AffinePointTarget p2, bool = false) {
-        return curve_op(OP_CADD, p1, p2);
+    // b is always "random-access index != 0" on the supported circuits; it is derived from p2's ref.
+    // not_b_aux: aux column of not(b) -- the four mul_biguint_by_bool products follow it (gadgets/curve.rs:232-238)
+    AffinePointTarget curve_conditional_add(AffinePointTarget p1, AffinePointTarget p2, u32 not_b_aux, bool range_check = false) {
+        return curve_op(OP_CADD, p1, p2, range_check, not_b_aux);
     }
     AffinePointTarget constant_affine_point(int which) {
         const Consts& C = consts();
+        (void)C;
         return {make_ref(R_CONST, (u32)which), true, AUX_SRC_CONST | (u32)(2 * which), AUX_SRC_CONST | (u32)(2 * which + 1),
-                const_num_limbs(C.cpts[which].x), const_num_limbs(C.cpts[which].y)};
+                const_num_limbs(const_value((u32)(2 * which))), const_num_limbs(const_value((u32)(2 * which + 1)))};
     }
 
     // ---- fixed_base_curve_mul_circuit(builder, G, scalar) ----
@@ -156,11 +174,13 @@ public:
         for (int w = 0; w < FB_WINDOWS; w++) {
             Scope s(this, "win" + std::to_string(w));
             // is_equal(limb, zero), not, random_access_curve_points(limb, muls_point), curve_conditional_add
-            AffinePointTarget r{make_ref(R_FBTAB, (u32)w), true};
+            // aux columns of this window: [is_zero, should_add, selected x (9), selected y (9), not_b, products ...]
+            const u32 base = aux_col_;
+            AffinePointTarget r{make_ref(R_FBTAB, (u32)w), true, AUX_SRC_AUX | (base + 2), AUX_SRC_AUX | (base + 2 + NL)};
             AuxItem it = select_item(AUX_FBWIN, result);
             it.a = scalar.col;
             it.b = (u32)w;
-            result = curve_conditional_add(result, r);
+            result = curve_conditional_add(result, r, base + 2 + 2 * NL);
             it.sumx = ops.back().col + COL_ADD_X3;
             it.sumy = ops.back().col + COL_ADD_Y3;
             aux(it, 2 + 2 * NL + 1 + 2 * NL + (u32)it.nlx + (u32)it.nly);
@@ -205,12 +225,14 @@ public:
             Scope s(this, "digit" + std::to_string(d));
             result = curve_repeated_double(result, 2);
             // mul_add(four, limb_m, limb_n), random_access_curve_points(index, pre), is_equal, not, conditional add
-            AffinePointTarget r{make_ref(R_MSMTAB, (u32)d), false};
+            // aux columns of this digit: [index, selected x (9), selected y (9), is_zero, should_add, not_b, products ...]
+            const u32 base = aux_col_;
+            AffinePointTarget r{make_ref(R_MSMTAB, (u32)d), false, AUX_SRC_AUX | (base + 1), AUX_SRC_AUX | (base + 1 + NL)};
             AuxItem it = select_item(AUX_MSMDIG, result);
             it.a = n.col;
             it.c = m.col;
             it.b = (u32)d;
-            result = curve_conditional_add(result, r);
+            result = curve_conditional_add(result, r, base + 1 + 2 * NL + 2);
             it.sumx = ops.back().col + COL_ADD_X3;
             it.sumy = ops.back().col + COL_ADD_Y3;
             aux(it, 1 + 2 * NL + 2 + 1 + 2 * NL + (u32)it.nlx + (u32)it.nly);
@@ -220,34 +242,33 @@ public:
     }
 
     // ---- CircuitBuilderGlv ----
-    void decompose_secp256k1_scalar() {
+    void decompose_secp256k1_scalar(NonNativeTarget k) {
         Scope s(this, "decompose");
         prog.sc.glv = (int32_t)col_;
-        NonNativeTarget f{FIELD_SCALAR};
         // GLVDecompositionGenerator outputs: k1[5], k2[5], k1_neg, k2_neg
-        const u32 g = gen(GEN_GLV, FIELD_SCALAR, 12);
+        const u32 g = gen(GEN_GLV, FIELD_SCALAR, 12, {k}, false);
         glv_k1_ = {FIELD_SCALAR, g, 5};
         glv_k2_ = {FIELD_SCALAR, g + 5, 5};
         glv_k1_neg_ = {g + 10};
         glv_k2_neg_ = {g + 11};
         NonNativeTarget k1 = nonnative_conditional_neg(glv_k1_, glv_k1_neg_);
         NonNativeTarget k2 = nonnative_conditional_neg(glv_k2_, glv_k2_neg_);
-        NonNativeTarget sb = mul_nonnative(f, k2);
+        NonNativeTarget sb = mul_nonnative(constant_nonnative(FIELD_SCALAR, CONSTV_GLV_S), k2);
         add_nonnative(sb, k1, true);
     }
-    AffinePointTarget glv_mul(int chain_slot_base_hint = 0) {
-        (void)chain_slot_base_hint;
-        decompose_secp256k1_scalar();
-        NonNativeTarget b{FIELD_BASE};
+    // p = (px, py): the caller's point (9-limb virtual targets); k: the scalar target
+    AffinePointTarget glv_mul(NonNativeTarget k) {
+        decompose_secp256k1_scalar(k);
+        NonNativeTarget px{FIELD_BASE, AUX_SRC_INPUT | INPUT_PX, NL};
         NonNativeTarget py{FIELD_BASE, AUX_SRC_INPUT_PY, NL};   // the caller's pk.y target (9 limbs)
         prog.sc.beta_x = (int32_t)col_;
-        NonNativeTarget beta_px = mul_nonnative(b, b, true);
+        NonNativeTarget beta_px = mul_nonnative(constant_nonnative(FIELD_BASE, CONSTV_GLV_BETA), px, true);
         prog.sc.neg_p = (int32_t)col_;
         NonNativeTarget y1 = nonnative_conditional_neg(py, glv_k1_neg_, true);  // curve_conditional_neg(p, k1_neg)
         prog.sc.neg_sp = (int32_t)col_;
         NonNativeTarget y2 = nonnative_conditional_neg(py, glv_k2_neg_, true);  // curve_conditional_neg(sp, k2_neg)
         Scope s(this, "msm");
-        AffinePointTarget p{make_ref(R_SLOT, SLOT_P_PLACEHOLDER), true, AUX_SRC_NONE, y1.col};
+        AffinePointTarget p{make_ref(R_SLOT, SLOT_P_PLACEHOLDER), true, px.col, y1.col};
         AffinePointTarget sp{make_ref(R_SLOT, SLOT_SP_PLACEHOLDER), true, beta_px.col, y2.col};
         return curve_msm_circuit(p, sp, glv_k1_, glv_k2_);
     }
@@ -256,14 +277,16 @@ public:
     void verify_secp256k1_message_circuit() {
         prog.full_verify = 1;
         prog.sc.assert_valid = (int32_t)col_;
-        curve_assert_valid();
-        NonNativeTarget s{FIELD_SCALAR};
+        AffinePointTarget pk{0, true, AUX_SRC_INPUT | INPUT_PX, AUX_SRC_INPUT_PY};
+        curve_assert_valid(pk);
+        NonNativeTarget s{FIELD_SCALAR, AUX_SRC_INPUT | INPUT_S, NL}, msg{FIELD_SCALAR, AUX_SRC_INPUT | INPUT_MSG, NL},
+            r{FIELD_SCALAR, AUX_SRC_INPUT | INPUT_R, NL};
         prog.sc.inv_s = (int32_t)col_;
         NonNativeTarget c = inv_nonnative(s);
         prog.sc.u1 = (int32_t)col_;
-        NonNativeTarget u1 = mul_nonnative(s, c, true);
+        NonNativeTarget u1 = mul_nonnative(msg, c, true);
         prog.sc.u2 = (int32_t)col_;
-        mul_nonnative(s, c, true);
+        NonNativeTarget u2 = mul_nonnative(r, c, true);
         int c0 = (int)ops.size();
         AffinePointTarget point1, point2;
         {
@@ -273,7 +296,7 @@ public:
         int c1 = (int)ops.size();
         {
             Scope sc(this, "glv_mul");
-            point2 = glv_mul();
+            point2 = glv_mul(u2);
         }
         int c2 = (int)ops.size();
         {
@@ -294,7 +317,7 @@ public:
     void glv_mul_circuit() {
         prog.full_verify = 0;
         prog.sc.assert_valid = prog.sc.inv_s = prog.sc.u1 = prog.sc.u2 = -1;
-        glv_mul();
+        glv_mul(NonNativeTarget{FIELD_SCALAR, AUX_SRC_INPUT | INPUT_MSG, NL});   // k travels in the msg slot (p2e_glv_mul_witness_batch)
         prog.num_chains = 1;
         prog.chain_begin[0] = 0;
         prog.chain_end[0] = (int)ops.size();
@@ -335,11 +358,21 @@ private:
         for (size_t i = 0; i < path_.size(); i++) s += (i ? "/" : "") + path_[i];
         return s;
     }
-    u32 gen(int kind, int field, u32 ncols) {   // returns the generator's first column
-        gens.push_back({kind, field, col_, ncols, label()});
+    u32 gen(int kind, int field, u32 ncols, const std::vector<NonNativeTarget>& operands, bool range_check) {
+        GenOp g{kind, field, col_, ncols, label()};   // returns the generator's first column
+        g.nops = (int)operands.size();
+        assert(g.nops <= 4);
+        for (int k = 0; k < g.nops; k++) {
+            g.src[k] = operands[(size_t)k].col;
+            g.nl[k] = (uint8_t)operands[(size_t)k].nl;
+        }
+        g.range_check = range_check;
+        gens.push_back(g);
         col_ += ncols;
         return col_ - ncols;
     }
+    static NonNativeTarget x_of(const AffinePointTarget& p) { return {FIELD_BASE, p.xcol, p.nlx}; }
+    static NonNativeTarget y_of(const AffinePointTarget& p) { return {FIELD_BASE, p.ycol, p.nly}; }
     void aux(AuxItem it, u32 ncols) {
         it.aux_col = aux_col_;
         it.ncols = ncols;
@@ -357,6 +390,19 @@ private:
         it.nly = (uint8_t)p1.nly;
         return it;
     }
+public:
+    // the value behind a constant source code AUX_SRC_CONST | id (aux.hpp)
+    static U256 const_value(u32 id) {
+        const Consts& C = consts();
+        if (id < 2 * NUM_CONST_PTS) return (id & 1) ? C.cpts[id >> 1].y : C.cpts[id >> 1].x;
+        if (id == CONSTV_B7) return u256_small(7);                                   // curve/secp256k1.rs:16
+        if (id == CONSTV_GLV_S)                                                      // curve/glv.rs:18-23
+            return u256_from_u64(16069571880186789234ull, 1310022930574435960ull, 11900229862571533402ull, 6008836872998760672ull);
+        if (id == CONSTV_GLV_BETA)                                                   // curve/glv.rs:11-16
+            return u256_from_u64(13923278643952681454ull, 11308619431505398165ull, 7954561588662645993ull, 8856726876819556112ull);
+        return u256_zero();                                                          // CONSTV_ZERO
+    }
+private:
     static int const_num_limbs(const U256& v) {   // constant_biguint gadgets/biguint.rs:165-175 via convert_base :27-51
         u32 l[NL];
         split29(v, l);
@@ -364,7 +410,7 @@ private:
         while (n > 0 && l[n - 1] == 0) n--;
         return n;
     }
-    AffinePointTarget curve_op(OpKind kind, AffinePointTarget p1, AffinePointTarget p2) {
+    AffinePointTarget curve_op(OpKind kind, AffinePointTarget p1, AffinePointTarget p2, bool range_check, u32 not_b_aux = 0) {
         OpDesc d{};
         d.kind = kind;
         d.flags = (uint8_t)((p1.z_one ? F_Z1ONE : 0) | ((kind != OP_DBL && p2.z_one) ? F_Z2ONE : 0));
@@ -372,35 +418,41 @@ private:
         d.ref2 = kind == OP_DBL ? 0 : p2.ref;
         d.col = col_;
         u32 t = (u32)ops.size();
-        NonNativeTarget f{FIELD_BASE};
+        const NonNativeTarget x1 = x_of(p1), y1 = y_of(p1), x2 = x_of(p2), y2 = y_of(p2);
+        NonNativeTarget x3, y3;
         if (kind == OP_DBL) {  // gadgets/curve.rs:160-185
-            add_nonnative(f, f);
-            inv_nonnative(f);
-            mul_nonnative(f, f);
-            add_many_nonnative({f, f, f, f});
-            mul_nonnative(f, f);
-            mul_nonnative(f, f);
-            add_nonnative(f, f);
-            sub_nonnative(f, f);
-            sub_nonnative(f, f);
-            mul_nonnative(f, f);
-            sub_nonnative(f, f);
-        } else {  // gadgets/curve.rs:202-223
-            sub_nonnative(f, f);
-            sub_nonnative(f, f);
-            inv_nonnative(f);
-            mul_nonnative(f, f);
-            mul_nonnative(f, f);
-            add_nonnative(f, f);
-            sub_nonnative(f, f);
-            sub_nonnative(f, f);
-            mul_nonnative(f, f);
-            sub_nonnative(f, f);
-            if (kind == OP_CADD) {  // gadgets/curve.rs:225-243
-                add_nonnative(f, f);
-                add_nonnative(f, f);
+            NonNativeTarget dy = add_nonnative(y1, y1);
+            NonNativeTarget idy = inv_nonnative(dy);
+            NonNativeTarget xx = mul_nonnative(x1, x1);
+            NonNativeTarget tr = add_many_nonnative({xx, xx, xx, constant_nonnative(FIELD_BASE, CONSTV_ZERO)});
+            NonNativeTarget lam = mul_nonnative(tr, idy);
+            NonNativeTarget lam2 = mul_nonnative(lam, lam);
+            NonNativeTarget xd = add_nonnative(x1, x1);
+            x3 = sub_nonnative(lam2, xd, range_check);
+            NonNativeTarget xdf = sub_nonnative(x1, x3);
+            NonNativeTarget lx = mul_nonnative(lam, xdf);
+            y3 = sub_nonnative(lx, y1, range_check);
+        } else {  // gadgets/curve.rs:202-223; a conditional add computes the sum unchecked (:233) ...
+            const bool rc = kind == OP_CADD ? false : range_check;
+            NonNativeTarget u = sub_nonnative(y2, y1);
+            NonNativeTarget v = sub_nonnative(x2, x1);
+            NonNativeTarget vinv = inv_nonnative(v);
+            NonNativeTarget sl = mul_nonnative(u, vinv);
+            NonNativeTarget s2 = mul_nonnative(sl, sl);
+            NonNativeTarget xs = add_nonnative(x2, x1);
+            x3 = sub_nonnative(s2, xs, rc);
+            NonNativeTarget xd = sub_nonnative(x1, x3);
+            NonNativeTarget pr = mul_nonnative(sl, xd);
+            y3 = sub_nonnative(pr, y1, rc);
+            if (kind == OP_CADD) {  // ... then selects: add(sum.x * b, p1.x * not_b), add(sum.y * b, p1.y * not_b)  :234-240
+                const u32 xt = not_b_aux + 1, yt = xt + NL, xf = yt + NL, yf = xf + (u32)p1.nlx;
+                const int F = FIELD_BASE;
+                add_nonnative({F, AUX_SRC_AUX | xt, NL}, {F, AUX_SRC_AUX | xf, p1.nlx}, range_check);
+                add_nonnative({F, AUX_SRC_AUX | yt, NL}, {F, AUX_SRC_AUX | yf, p1.nly}, range_check);
             }
         }
+        (void)x3;
+        (void)y3;
         AffinePointTarget out;
         if (kind == OP_CADD) {
             d.cadd_idx = (uint16_t)num_cadd_;

@@ -9,6 +9,7 @@
 #include "../../plonky2-ecdsa_amd/csrc/consts.hpp"
 #include "../../plonky2-ecdsa_amd/csrc/pipeline.hpp"
 #include "../../plonky2-ecdsa_amd/csrc/prims.hpp"
+#include "../../plonky2-ecdsa_amd/csrc/quad.hpp"
 #include "../../plonky2-ecdsa_amd/csrc/schedule.hpp"
 
 using namespace p2e;
@@ -29,7 +30,7 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     std::vector<U256> PX((size_t)G.num_slots * n), PY((size_t)G.num_slots * n), PZ((size_t)G.num_slots * n),
         PW((size_t)G.num_ops * n), PREF((size_t)G.num_ops * n), AX((size_t)G.num_slots * n), AY((size_t)G.num_slots * n);
     std::vector<uint8_t> dig4((size_t)FB_WINDOWS * n), dig2((size_t)MSM_DIGITS * n), valid8(n);
-    std::vector<uint16_t> dyn((size_t)G.num_cadd * n), src((size_t)G.num_ops * 2 * n);
+    std::vector<uint16_t> dyn((size_t)G.num_cadd * n), src((size_t)G.num_ops * 2 * n), msrc((size_t)MSM_DIGITS * n);
     std::vector<u32> err32(n);
     Buffers B{};
     B.msg = msg; B.r = r; B.s = s; B.pkx = pkx; B.pky = pky;
@@ -43,7 +44,7 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     B.err = err32.data(); B.valid = valid8.data();
     B.PX = PX.data(); B.PY = PY.data(); B.PZ = PZ.data(); B.PW = PW.data(); B.PREF = PREF.data();
     B.AX = AX.data(); B.AY = AY.data();
-    B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data(); B.src = src.data();
+    B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data(); B.src = src.data(); B.msrc = msrc.data();
     B.cpts = C.cpts; B.fbtab = C.fbtab.data(); B.ops = sb.ops.data();
 #pragma omp parallel for
     for (long long i = 0; i < (long long)n; i++) body_scalar<E>(G, B, (size_t)i);
@@ -51,7 +52,17 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     // phases B and C are interleaved with the following pieces of the chain
     // chunk >= piece length: one batch per piece using phase A's prefix products (what the GPU launches);
     // smaller chunks re-run the forward pass inside phase B (arbitrary batching must not change any output)
-    auto binv = [&](int lo, int hi) {
+    // chunk < 0: the small-batch plan of run_program() (quad.hpp): four lanes per signature walk the chains, the
+    // window table is walked as rows, every inversion batch is cut into -chunk sub-ranges
+    const bool quad = chunk < 0;
+    const int split = quad ? -chunk : 1;
+    auto binv = [&](int lo, int hi, bool have_prefix = true) {
+        if (quad) {
+#pragma omp parallel for
+            for (long long i = 0; i < (long long)n; i++)
+                for (int q = 0; q < split; q++) body_batch_inv_split(G, B, (size_t)i, lo, hi, have_prefix, q, split);
+            return;
+        }
         if (chunk >= hi - lo) {
 #pragma omp parallel for
             for (long long i = 0; i < (long long)n; i++) body_batch_inv(G, B, (size_t)i, lo, hi, true);
@@ -65,7 +76,13 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     };
     auto chain = [&](int lo, int hi, bool table_affine, bool cont = false) {
 #pragma omp parallel for
-        for (long long i = 0; i < (long long)n; i++) body_chain_range(G, B, (size_t)i, lo, hi, table_affine, cont);
+        for (long long i = 0; i < (long long)n; i++) {
+            if (quad)   // every role walks the whole range (the host form of a level computes all four products) and
+                        // writes only its own share of the scratch outputs
+                for (int role = 0; role < 4; role++) body_chain_range_quad(G, B, (size_t)i, role, lo, hi, table_affine, cont);
+            else
+                body_chain_range(G, B, (size_t)i, lo, hi, table_affine, cont);
+        }
     };
     auto expand = [&](int lo, int hi) {
 #pragma omp parallel for
@@ -90,8 +107,8 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     {
         const int lo0 = G.chain_begin[0], hi0 = G.chain_end[0], lb = G.msm_loop_begin, iters = G.msm_loop_iters;
         const int le = lb + 3 * iters, R = run_iters > 0 ? run_iters : 1, groups = 3;
-        if (G.num_chains == 1) {
-            // glv_mul alone: the window table as rows of independent sub-chains, as the GPU walks it there
+        if (G.num_chains == 1 || quad) {
+            // glv_mul alone (and small batches): the window table as rows of independent sub-chains, as the GPU walks it there
             // (body_chain_rows), prefix products left to phase B
             auto rows = [&](int lo, int nrows, int count) {
 #pragma omp parallel for
@@ -101,8 +118,12 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
             rows(lo0, 2, 4);
             rows(lo0 + 8, 6, 1);
             rows(lo0 + 14, 9, 1);
+            if (quad) {
+                binv(lo0, lb, false);
+            } else {
 #pragma omp parallel for
-            for (long long i = 0; i < (long long)n; i++) body_batch_inv(G, B, (size_t)i, lo0, lb, false);
+                for (long long i = 0; i < (long long)n; i++) body_batch_inv(G, B, (size_t)i, lo0, lb, false);
+            }
         } else {
             chain(lo0, lb, false);
             binv(lo0, lb);
@@ -197,7 +218,7 @@ long emu_verify_only(const uint8_t* msg, const uint8_t* r, const uint8_t* s, con
     std::vector<U256> PX((size_t)G.num_slots * n), PY((size_t)G.num_slots * n), PZ((size_t)G.num_slots * n),
         PW((size_t)G.num_ops * n), PREF((size_t)G.num_ops * n), AX((size_t)G.num_slots * n), AY((size_t)G.num_slots * n);
     std::vector<uint8_t> dig4((size_t)FB_WINDOWS * n), dig2((size_t)MSM_DIGITS * n), valid8(n);
-    std::vector<uint16_t> dyn((size_t)G.num_cadd * n), src((size_t)G.num_ops * 2 * n);
+    std::vector<uint16_t> dyn((size_t)G.num_cadd * n), src((size_t)G.num_ops * 2 * n), msrc((size_t)MSM_DIGITS * n);
     std::vector<u32> err32(n);
     Buffers B{};
     B.msg = msg; B.r = r; B.s = s; B.pkx = pkx; B.pky = pky;
@@ -205,7 +226,7 @@ long emu_verify_only(const uint8_t* msg, const uint8_t* r, const uint8_t* s, con
     B.err = err32.data(); B.valid = valid8.data();
     B.PX = PX.data(); B.PY = PY.data(); B.PZ = PZ.data(); B.PW = PW.data(); B.PREF = PREF.data();
     B.AX = AX.data(); B.AY = AY.data();
-    B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data(); B.src = src.data();
+    B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data(); B.src = src.data(); B.msrc = msrc.data();
     B.cpts = C.cpts; B.fbtab = C.fbtab.data(); B.ops = sb.ops.data();
 #pragma omp parallel for
     for (long long i = 0; i < (long long)n; i++) {

@@ -78,9 +78,17 @@ def test_structured_operands(gpu, ora):
     pc.check_structured_mul_add_sub(gpu, ora, count=20000)
 
 
-def test_verify_random_batch_ragged(gpu, ora):
-    """n = 301: not a multiple of the wavefront / workgroup size."""
+@pytest.mark.parametrize("plan", ["quad", "lane_per_signature", "quad_split8"])
+def test_verify_random_batch_ragged(ora, monkeypatch, plan):
+    """n = 301: not a multiple of the wavefront / workgroup size (nor of the 64 signatures a quad workgroup holds).
+    Both forms of phases A / B: four lanes per signature with split inversion batches (the default below 24 576
+    signatures per call, csrc/quad.hpp) and one lane per signature (what a 2^16 batch runs)."""
     import plonky2_ecdsa_amd as p2e
+    from backends import GpuBackend
+    monkeypatch.setenv("P2E_QUAD_MAX_N", "0" if plan == "lane_per_signature" else "1000000")
+    if plan == "quad_split8":
+        monkeypatch.setenv("P2E_BINV_SPLIT_LOG2", "3")
+    gpu = GpuBackend()
     arrs = p2e.synth_signatures(seed=77, n=301)
     want, werr, wflags = ora.verify(*arrs)
     got, err, valid = gpu.verify(*arrs)

@@ -209,6 +209,30 @@ def test_batch_inversion_chunking_is_output_invariant(chunk):
     assert not err.any() and valid.all() and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("split", [1, 4, 5])
+def test_quad_lanes_and_split_inversion_batches_are_output_invariant(split):
+    """csrc/quad.hpp (the small-batch plan): the chains walked by four lanes per signature (levels of four
+    multiplications, host form), the window table as rows, every inversion batch cut into `split` sub-ranges --
+    same columns, error flags and verdicts as the oracle, for both programs, with an inverse-of-zero element."""
+    emu, ora = EmuBackend(), OracleBackend()
+    arrs = [a.copy() for a in p2e.synth_signatures(seed=19, n=9)]
+    arrs[1][3, 0] ^= 1
+    rx, ry = R.rando_point()
+    arrs[3][5] = np.frombuffer(int(rx).to_bytes(32, "little"), dtype=np.uint8)
+    arrs[4][5] = np.frombuffer(int((-ry) % R.P).to_bytes(32, "little"), dtype=np.uint8)
+    want, werr, wflags = ora.verify(*arrs)
+    got, err, valid = emu.verify(*arrs, chunk=-split, run_iters=0)
+    ok = werr == 0
+    assert np.array_equal(err != 0, werr != 0) and err[5] & R.ERR_INVERSE_OF_ZERO
+    assert np.array_equal(got[:, ok], want[:, ok]) and np.array_equal(valid[ok], wflags[ok])
+    rng = R.SplitMix64(20)
+    k = oracle_c.pack256([rng.below(R.N) for _ in range(9)])
+    want, werr, _ = ora.glv_mul(arrs[3], arrs[4], k)
+    got, err, _ = emu.glv_mul(arrs[3], arrs[4], k, chunk=-split, run_iters=4)
+    ok = werr == 0
+    assert np.array_equal(err != 0, werr != 0) and np.array_equal(got[:, ok], want[:, ok])
+
+
 @pytest.mark.parametrize("run_iters", [0, 1, 3, 73])
 def test_expansion_run_length_is_output_invariant(run_iters):
     """Phase C walks MSM-loop iterations in runs (phase B skips the affine conversion inside a run): any run

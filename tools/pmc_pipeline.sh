@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 PY=$(readlink -f "$(which python3)")
 rm -rf gpurun_out/pmcp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d gpurun_out/pmcp -o p -- $PY bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/pmcp.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d gpurun_out/pmcp -o p -- $PY bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-limb-split --check 0 ${BENCH_ARGS} > /dev/null 2> gpurun_out/pmcp.err
 python3 - <<'PYEOF'
 import csv, collections
 rows = list(csv.DictReader(open("gpurun_out/pmcp/p_counter_collection.csv")))
