@@ -171,6 +171,30 @@ typedef struct p2e_aux_desc {
 long p2e_aux_describe(int program, p2e_aux_desc *out, size_t cap);
 long p2e_aux_num_cols(int program);
 
+/* ---- constraint-block columns ---------------------------------------------- */
+/* The values of the targets the plonky2_ux U29 gates fill INSIDE the constraint blocks of the non-native gadgets
+ * (gadgets/nonnative.rs:262-273 add, :330-351 add_many, :373-386 sub, :518-530 inv, :462-463 mul's range check): what
+ * add_biguint / sub_biguint / mul_biguint (gadgets/biguint.rs:240-323) receive back from add_many_ux, sub_ux, mul_ux
+ * and add_uxs_with_carry (limb, carry / borrow), the mul_biguint_by_bool products modulus * overflow (:360-374), and
+ * the cmp_biguint result of a range-checked gadget -- generator by generator, in the order the builder makes the
+ * calls (p2e_ux_describe).  Derived on the GPU from the finished matrices `cols` and `aux` (p2e_aux_witness_batch),
+ * the packed inputs and the circuit constants through the wiring of p2e_schedule_wiring.
+ * ux[P2E_VERIFY_UX_COLS or P2E_GLV_MUL_UX_COLS][ld_ux]: u64 (ux_u32 = 0) or u32 (every value is < 2^29).
+ * glv_mul program: k32 travels in msg32, r32 / s32 are ignored (may be NULL).  err[i] gets P2E_ERR_LIMB_RANGE where an
+ * operand limb is not a U29 value.  plonky2_ux is not available offline: the gates are modelled by what they constrain
+ * (oracle/check_circuit.py holds the same model; "parity unpinned"). */
+#define P2E_VERIFY_UX_COLS 249385
+#define P2E_GLV_MUL_UX_COLS 194361
+long p2e_ux_witness_batch(p2e_ctx *ctx, int program, const uint8_t *msg32, const uint8_t *r32, const uint8_t *s32,
+                          const uint8_t *pkx32, const uint8_t *pky32, const uint64_t *cols, size_t ld, const uint64_t *aux,
+                          size_t ld_aux, void *ux, int ux_u32, size_t ld_ux, size_t n, uint8_t *err);
+typedef struct p2e_ux_desc {
+    uint32_t first_col, num_cols; /* this generator's block (num_cols = 0: none, e.g. an unchecked mul) */
+} p2e_ux_desc;
+/* one entry per generator, same index as p2e_schedule_describe; returns the generator count */
+long p2e_ux_describe(int program, p2e_ux_desc *out, size_t cap);
+long p2e_ux_num_cols(int program);
+
 /* ---- layout helper --------------------------------------------------------------------------------- */
 /* cols[ncols][ld] (column-major over the batch) -> rows[n][row_ld], one contiguous witness per signature:
  * what a per-signature PartialWitness fill (pw.set_biguint_target ... gadgets/biguint.rs:454-463 per target,

@@ -39,6 +39,8 @@ VERIFY_COLS = 82615
 GLV_MUL_COLS = 65243
 VERIFY_AUX_COLS = 8959      # built-in-generator columns (include/p2e.h p2e_aux_witness_batch)
 GLV_MUL_AUX_COLS = 4738
+VERIFY_UX_COLS = 249385     # constraint-block (U29 gate) columns (include/p2e.h p2e_ux_witness_batch)
+GLV_MUL_UX_COLS = 194361
 PROGRAM_VERIFY, PROGRAM_GLV_MUL = 0, 1
 
 # every symbol include/p2e.h declares
@@ -47,7 +49,7 @@ EXPORTS = (
     "p2e_mul_witness_batch", "p2e_checksum_witness_batch", "p2e_add_witness_batch", "p2e_sub_witness_batch",
     "p2e_add_many_witness_batch", "p2e_inv_witness_batch", "p2e_glv_decompose_batch", "p2e_limb_split",
     "p2e_limb_pack", "p2e_ecdsa_verify_witness_batch", "p2e_glv_mul_witness_batch", "p2e_columns_to_rows",
-    "p2e_schedule_describe", "p2e_schedule_wiring", "p2e_wiring_const",
+    "p2e_schedule_describe", "p2e_schedule_wiring", "p2e_wiring_const", "p2e_ux_witness_batch", "p2e_ux_describe", "p2e_ux_num_cols",
     "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
     "p2e_compact_layout", "p2e_columns_compact", "p2e_ecdsa_verify_witness_compact_batch",
     "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch", "p2e_compact_to_rows", "p2e_ecdsa_verify_batch", "p2e_biguint_div_rem_batch",
@@ -174,6 +176,26 @@ def wiring_const(const_id: int):
     if nl < 0:
         raise P2EError("unknown constant id")
     return int.from_bytes(bytes(buf), "little"), int(nl)
+
+
+class _UxDesc(C.Structure):
+    _fields_ = [("first_col", C.c_uint32), ("num_cols", C.c_uint32)]
+
+
+def ux_describe(program: int = PROGRAM_VERIFY):
+    """Per generator (order of schedule_describe): (first_col, num_cols) of its block in the constraint-block matrix."""
+    L = lib()
+    L.p2e_ux_describe.restype = C.c_long
+    n = L.p2e_ux_describe(C.c_int(program), None, C.c_size_t(0))
+    arr = (_UxDesc * n)()
+    L.p2e_ux_describe(C.c_int(program), arr, C.c_size_t(n))
+    return [(int(d.first_col), int(d.num_cols)) for d in arr]
+
+
+def ux_num_cols(program: int = PROGRAM_VERIFY) -> int:
+    L = lib()
+    L.p2e_ux_num_cols.restype = C.c_long
+    return int(L.p2e_ux_num_cols(C.c_int(program)))
 
 
 def schedule_num_cols(program: int = PROGRAM_VERIFY) -> int:
@@ -446,6 +468,35 @@ class Context:
         bad = self._check(self._L.p2e_aux_witness_batch(self._h, C.c_int(program), _ptr(pky), _ptr(cols), C.c_size_t(ld),
                                                         _ptr(aux), C.c_size_t(ld_aux), C.c_size_t(n), _ptr(err)))
         return aux, err, bad
+
+    def ux_witness_batch(self, program, inputs, cols, aux, n=None, ld=None, ld_aux=None, ux=None, ld_ux=None, err=None, u32=True):
+        """Constraint-block columns (what the U29 gates inside add / sub / add_many / inv / the
+        range checks hand back, in builder-call order) from the finished witness and aux matrices.
+        inputs: (msg, r, s, pk.x, pk.y) for the verify program, (pk.x, pk.y, k) for glv_mul.  (249385 | 194361, n)."""
+        if program == PROGRAM_VERIFY:
+            msg, r, s, pkx, pky = inputs
+        else:
+            pkx, pky, msg = inputs
+            r = s = None
+        n = n if n is not None else self._shape(pky)[0]
+        ld = ld if ld is not None else _ld(cols)
+        ld_aux = ld_aux if ld_aux is not None else _ld(aux)
+        k = VERIFY_UX_COLS if program == PROGRAM_VERIFY else GLV_MUL_UX_COLS
+        if ux is None:
+            if self.host_pointers:
+                ux = np.zeros((k, n), dtype=np.uint32 if u32 else np.uint64)
+            else:
+                import torch
+                ux = torch.empty((k, n), dtype=torch.int32 if u32 else torch.int64, device=f"cuda:{self.device}")
+        else:
+            u32 = (ux.dtype == np.uint32) if isinstance(ux, np.ndarray) else (ux.element_size() == 4)
+        ld_ux = ld_ux if ld_ux is not None else _ld(ux)
+        err = err if err is not None else self._vec(n, np.uint8)
+        self._L.p2e_ux_witness_batch.restype = C.c_long
+        bad = self._check(self._L.p2e_ux_witness_batch(self._h, C.c_int(program), _ptr(msg), _ptr(r), _ptr(s), _ptr(pkx), _ptr(pky),
+                                                       _ptr(cols), C.c_size_t(ld), _ptr(aux), C.c_size_t(ld_aux), _ptr(ux),
+                                                       C.c_int(1 if u32 else 0), C.c_size_t(ld_ux), C.c_size_t(n), _ptr(err)))
+        return ux, err, bad
 
     def columns_compact(self, program, cols, n=None, ld=None, narrow=None, wide=None, err=None, ld_narrow=None, ld_wide=None):
         """Repack a finished witness matrix for transfers: (narrow u32 (num_narrow, n), wide u64 (num_wide, n), err, bad).

@@ -113,6 +113,12 @@ __global__ __launch_bounds__(BS) void k_aux(AuxArgs A, size_t first) {
     size_t i = lane_sig<(MODE & 1) != 0>(first);
     if ((MODE & 1) || i < A.n) body_aux<typename AuxEmitOf<MODE>::type>(A, (int)blockIdx.y, i);
 }
+// constraint-block columns from the finished matrices: one (signature, generator) per lane (ux.hpp)
+template <int MODE>
+__global__ __launch_bounds__(BS) void k_ux(UxArgs A, size_t first) {
+    size_t i = lane_sig<(MODE & 1) != 0>(first);
+    if ((MODE & 1) || i < A.n) body_ux<typename AuxEmitOf<MODE>::type>(A, (int)blockIdx.y, i);
+}
 // err words -> caller's err bytes, valid bytes, flagged count
 __global__ __launch_bounds__(BS) void k_finalize(const u32* err32, const uint8_t* valid8, uint8_t* err_out,
                                                  uint8_t* valid_out, size_t n, unsigned long long* counter) {
@@ -368,6 +374,11 @@ struct DeviceProgram {
     AuxTables aux_tab{};
     AuxItem* d_aux_items = nullptr;
     AuxTables* d_aux_tab = nullptr;
+    // constraint-block columns (ux.hpp)
+    std::vector<UxItem> ux_items;
+    std::vector<u32> ux_first, ux_count;
+    u32 num_ux_cols = 0;
+    UxItem* d_ux_items = nullptr;
     // compact container (p2e_columns_compact): per-column slot, narrow / wide column counts
     std::vector<u32> compact_map;
     u32 num_narrow = 0, num_wide = 0;
@@ -407,8 +418,12 @@ struct p2e_ctx {
     // (k_chains_quad) and every inversion batch is cut into 2^binv_split_log2 sub-ranges (k_batch_inv_split)
     size_t quad_max_n = 24576;
     int binv_split_log2 = 2;
+    // small-batch plan: dynamic LDS bytes requested by the expansion kernels (they do not use it): caps how many of
+    // their workgroups share a CU, so that the register file keeps room for the chain waves queued behind them
+    unsigned expand_lds_small = 160000;
     Aff* d_cpts = nullptr;
     Aff* d_fbtab = nullptr;
+    U256* d_constv = nullptr;   // circuit constants by id (AUX_SRC_CONST | id), for the constraint-block pass
     DeviceProgram progs[2];
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -443,6 +458,10 @@ static const DeviceProgram& host_program(int program) {
         P[0].aux_items = b0.aux_items;
         P[0].aux_gens = b0.aux_gens;
         P[0].aux_tab = b0.aux_tab;
+        P[0].ux_items = b0.ux_items;
+        P[0].ux_first = b0.ux_first;
+        P[0].ux_count = b0.ux_count;
+        P[0].num_ux_cols = b0.num_ux_cols;
         build_compact_map(P[0]);
         host::ScheduleBuilder b1;
         b1.glv_mul_circuit();
@@ -451,6 +470,10 @@ static const DeviceProgram& host_program(int program) {
         P[1].aux_items = b1.aux_items;
         P[1].aux_gens = b1.aux_gens;
         P[1].aux_tab = b1.aux_tab;
+        P[1].ux_items = b1.ux_items;
+        P[1].ux_first = b1.ux_first;
+        P[1].ux_count = b1.ux_count;
+        P[1].num_ux_cols = b1.num_ux_cols;
         build_compact_map(P[1]);
     });
     return P[program];
@@ -537,12 +560,19 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     HIP_TRY(hipMalloc(&c->d_fbtab, sizeof(Aff) * C.fbtab.size()));
     HIP_TRY(hipMemcpy(c->d_cpts, C.cpts, sizeof(Aff) * NUM_CONST_PTS, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_fbtab, C.fbtab.data(), sizeof(Aff) * C.fbtab.size(), hipMemcpyHostToDevice));
+    {
+        U256 cv[NUM_CONSTV];
+        for (u32 id = 0; id < NUM_CONSTV; id++) cv[id] = host::ScheduleBuilder::const_value(id);
+        HIP_TRY(hipMalloc(&c->d_constv, sizeof cv));
+        HIP_TRY(hipMemcpy(c->d_constv, cv, sizeof cv, hipMemcpyHostToDevice));
+    }
     if (const char* env = getenv("P2E_RUN_ITERS")) {
         int v = atoi(env);
         if (v >= 0 && v <= MSM_DIGITS) c->run_iters = v;
     }
     if (const char* env = getenv("P2E_RUNS_MIN_N")) c->runs_min_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_QUAD_MAX_N")) c->quad_max_n = (size_t)strtoull(env, nullptr, 10);
+    if (const char* env = getenv("P2E_EXPAND_LDS_SMALL")) c->expand_lds_small = (unsigned)strtoul(env, nullptr, 10);
     if (const char* env = getenv("P2E_BINV_SPLIT_LOG2")) {
         int v = atoi(env);
         if (v >= 0 && v <= 4) c->binv_split_log2 = v;
@@ -558,6 +588,10 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         c->progs[p].aux_items = HP.aux_items;
         HIP_TRY(hipMalloc(&c->progs[p].d_aux_items, sizeof(AuxItem) * HP.aux_items.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_aux_items, HP.aux_items.data(), sizeof(AuxItem) * HP.aux_items.size(), hipMemcpyHostToDevice));
+        c->progs[p].ux_items = HP.ux_items;
+        c->progs[p].num_ux_cols = HP.num_ux_cols;
+        HIP_TRY(hipMalloc(&c->progs[p].d_ux_items, sizeof(UxItem) * HP.ux_items.size()));
+        HIP_TRY(hipMemcpy(c->progs[p].d_ux_items, HP.ux_items.data(), sizeof(UxItem) * HP.ux_items.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc(&c->progs[p].d_aux_tab, sizeof(AuxTables)));
         HIP_TRY(hipMemcpy(c->progs[p].d_aux_tab, &HP.aux_tab, sizeof(AuxTables), hipMemcpyHostToDevice));
         c->progs[p].num_narrow = HP.num_narrow;
@@ -613,7 +647,9 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_cpts);
     (void)hipFree(c->d_fbtab);
+    (void)hipFree(c->d_constv);
     for (auto& p : c->progs) {
+        (void)hipFree(p.d_ux_items);
         (void)hipFree(p.d_ops);
         (void)hipFree(p.d_ops_plain);
         (void)hipFree(p.d_aux_items);
@@ -1072,13 +1108,14 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
 #define LAUNCH_EMIT(KERNEL, PAIRED, GRID, STREAM, ...)                                                    \
     do {                                                                                                  \
         if (compact) {                                                                                    \
-            if (PAIRED) hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(BS), 0, STREAM, __VA_ARGS__);            \
-            else hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(BS), 0, STREAM, __VA_ARGS__);                   \
+            if (PAIRED) hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(BS), emit_lds, STREAM, __VA_ARGS__);     \
+            else hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(BS), emit_lds, STREAM, __VA_ARGS__);            \
         } else {                                                                                          \
-            if (PAIRED) hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(BS), 0, STREAM, __VA_ARGS__);            \
-            else hipLaunchKernelGGL(KERNEL<0>, GRID, dim3(BS), 0, STREAM, __VA_ARGS__);                   \
+            if (PAIRED) hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(BS), emit_lds, STREAM, __VA_ARGS__);     \
+            else hipLaunchKernelGGL(KERNEL<0>, GRID, dim3(BS), emit_lds, STREAM, __VA_ARGS__);            \
         }                                                                                                 \
     } while (0)
+    unsigned emit_lds = 0;   // dynamic LDS of the emitting kernels (only ever non-zero for the expansions of the small-batch plan)
     const size_t n_wide = wide_ok ? (n / BS) * BS : 0;
     const unsigned gx_wide = (unsigned)(n_wide / BS);
     const unsigned gx_tail = (unsigned)((n - n_wide + BS - 1) / BS);
@@ -1217,6 +1254,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         }
     c->n_expand = 0;
     bool used_c2 = false;
+    emit_lds = quad ? c->expand_lds_small : 0;
     for (int q = 0; q < ns; q++) {
         const int k = order[q];
         const Seg& sg = segs[k];
@@ -1439,9 +1477,80 @@ extern "C" long p2e_aux_witness_compact_batch(p2e_ctx* c, int program, const uin
     return run_aux(c, program, pky32, nullptr, 0, narrow, ld_narrow, aux32, true, ld_aux, n, err);
 }
 
+extern "C" long p2e_ux_witness_batch(p2e_ctx* c, int program, const uint8_t* msg32, const uint8_t* r32, const uint8_t* s32,
+                                     const uint8_t* pkx32, const uint8_t* pky32, const uint64_t* cols, size_t ld,
+                                     const uint64_t* aux, size_t ld_aux, void* ux, int ux_u32, size_t ld_ux, size_t n, uint8_t* err) {
+    if (bad_common(c, n, ld) || program < 0 || program > 1 || !msg32 || !pkx32 || !pky32 || (program == 0 && (!r32 || !s32)) ||
+        !cols || !aux || !ux || !err || ld_aux < n || ld_ux < n) {
+        if (c && (ld_aux < n || ld_ux < n)) set_error("ld_aux / ld_ux < n");
+        return P2E_E_INVALID;
+    }
+    if (n == 0) return 0;
+    const DeviceProgram& DP = c->progs[program];
+    Staged S(c);
+    msg32 = S.in(msg32, 32 * n);
+    if (r32) r32 = S.in(r32, 32 * n);
+    if (s32) s32 = S.in(s32, 32 * n);
+    pkx32 = S.in(pkx32, 32 * n);
+    pky32 = S.in(pky32, 32 * n);
+    cols = S.in(cols, (size_t)DP.prog.num_cols * ld * 8);
+    aux = S.in(aux, (size_t)DP.aux_tab.num_aux_cols * ld_aux * 8);
+    ux = S.out((char*)ux, (size_t)DP.num_ux_cols * ld_ux * (ux_u32 ? 4 : 8));
+    err = S.out(err, n);
+    if (S.rc) return S.done(S.rc);
+    if (int rc = ensure_scratch(c, n * sizeof(u32))) return S.done(rc);
+    ZERO_COUNTER(c);
+    u32* err32 = (u32*)c->scratch;
+    HIP_TRY(hipMemsetAsync(err32, 0, n * sizeof(u32), c->stream));
+    UxArgs A{};
+    A.cols = cols;
+    A.ld = ld;
+    A.aux = aux;
+    A.ald = ld_aux;
+    A.ux = ux;
+    A.uld = ld_ux;
+    A.n = n;
+    A.in[INPUT_PY] = pky32;
+    A.in[INPUT_PX] = pkx32;
+    A.in[INPUT_MSG] = msg32;
+    A.in[INPUT_R] = r32 ? r32 : msg32;
+    A.in[INPUT_S] = s32 ? s32 : msg32;
+    A.consts = c->d_constv;
+    A.items = DP.d_ux_items;
+    A.err = err32;
+    const unsigned gx = (unsigned)((n + BS - 1) / BS), items = (unsigned)DP.ux_items.size();
+    const bool wide_ok = (ld_ux % 2 == 0) && ((reinterpret_cast<uintptr_t>(ux) & (ux_u32 ? 7 : 15)) == 0) && !getenv("P2E_NARROW_STORES");
+    const size_t n_wide = wide_ok ? (n / BS) * BS : 0;
+    const dim3 gw((unsigned)(n_wide / BS), items), gt((unsigned)((n - n_wide + BS - 1) / BS), items);
+    if (ux_u32) {
+        if (n_wide) hipLaunchKernelGGL(k_ux<3>, gw, dim3(BS), 0, c->stream, A, (size_t)0);
+        if (n > n_wide) hipLaunchKernelGGL(k_ux<2>, gt, dim3(BS), 0, c->stream, A, n_wide);
+    } else {
+        if (n_wide) hipLaunchKernelGGL(k_ux<1>, gw, dim3(BS), 0, c->stream, A, (size_t)0);
+        if (n > n_wide) hipLaunchKernelGGL(k_ux<0>, gt, dim3(BS), 0, c->stream, A, n_wide);
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, err32, (const uint8_t*)nullptr, err, (uint8_t*)nullptr, n,
+                       c->d_counter);
+    c->have_phases = false;
+    return S.done(finish_call(c));
+}
+
 // ====================================================================================================
 // host-only entry points
 // ====================================================================================================
+extern "C" long p2e_ux_describe(int program, p2e_ux_desc* out, size_t cap) {
+    if (program < 0 || program > 1) return P2E_E_INVALID;
+    const DeviceProgram& P = host_program(program);
+    for (size_t i = 0; i < P.ux_first.size() && i < cap && out; i++) {
+        out[i].first_col = P.ux_first[i];
+        out[i].num_cols = P.ux_count[i];
+    }
+    return (long)P.ux_first.size();
+}
+extern "C" long p2e_ux_num_cols(int program) {
+    if (program < 0 || program > 1) return P2E_E_INVALID;
+    return (long)host_program(program).num_ux_cols;
+}
 extern "C" long p2e_aux_describe(int program, p2e_aux_desc* out, size_t cap) {
     if (program < 0 || program > 1) return P2E_E_INVALID;
     const auto& g = host_program(program).aux_gens;

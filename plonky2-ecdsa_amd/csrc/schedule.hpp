@@ -21,6 +21,7 @@
 
 #include "aux.hpp"
 #include "consts.hpp"
+#include "ux.hpp"
 #include "pipeline.hpp"
 
 namespace p2e {
@@ -72,6 +73,11 @@ public:
     std::vector<GenOp> gens;
     std::vector<OpDesc> ops;
     Program prog{};
+    // constraint-block columns (ux.hpp): one item per generator with a non-empty block, and per
+    // generator (same index as gens) its first ux column / column count
+    std::vector<UxItem> ux_items;
+    std::vector<u32> ux_first, ux_count;
+    u32 num_ux_cols = 0;
     // built-in-generator columns: items for k_aux + their column map
     std::vector<AuxItem> aux_items;
     std::vector<AuxGen> aux_gens;
@@ -483,6 +489,36 @@ private:
             fix(o.ref2);
         }
         for (auto& r : prog.msm_tab) fix(r);
+        // constraint-block columns, builder-call order = generator order
+        for (const GenOp& g : gens) {
+            u32 nc = 0;
+            UxItem it{};
+            it.field = (uint8_t)g.field;
+            it.nops = (uint8_t)g.nops;
+            it.range_check = g.range_check ? 1 : 0;
+            for (int k = 0; k < 4; k++) {
+                it.src[k] = g.src[k];
+                it.nl[k] = g.nl[k];
+            }
+            it.res_col = g.col;
+            switch (g.kind) {
+                case GEN_ADD: it.kind = UX_ADD; nc = UX_COLS_ADD; break;
+                case GEN_SUB: it.kind = UX_SUB; nc = UX_COLS_SUB; break;
+                case GEN_ADD_MANY: it.kind = UX_ADD_MANY; nc = UX_COLS_ADD_MANY; assert(g.nops == 4); break;
+                case GEN_INV: it.kind = UX_INV; nc = UX_COLS_INV; assert(g.nl[0] == NL); break;
+                case GEN_MUL: it.kind = UX_MUL; nc = 0; break;
+                default: nc = 0; it.range_check = 0; break;   // GLV decomposition: constrained through the ops after it
+            }
+            if (g.kind != GEN_GLV) nc += g.range_check ? 1u : 0u;
+            ux_first.push_back(num_ux_cols);
+            ux_count.push_back(nc);
+            if (nc) {
+                it.ux_col = num_ux_cols;
+                it.ncols = nc;
+                ux_items.push_back(it);
+            }
+            num_ux_cols += nc;
+        }
     }
 };
 

@@ -51,8 +51,24 @@ class EmuBackend:
         self.L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libp2e_emu.so"))
         for f in ("emu_verify", "emu_glv_mul", "emu_mul", "emu_checksum", "emu_add", "emu_sub", "emu_add_many",
                   "emu_inv", "emu_glv", "emu_split", "emu_pack", "emu_aux", "emu_aux_num_cols", "emu_verify_compact",
-                  "emu_glv_mul_compact", "emu_aux_compact", "emu_verify_only", "emu_div_rem"):
+                  "emu_glv_mul_compact", "emu_aux_compact", "emu_verify_only", "emu_div_rem", "emu_ux"):
             getattr(self.L, f).restype = C.c_long
+
+    def ux(self, program, inputs, cols, aux):
+        """constraint-block columns from finished matrices: (num_ux_cols, n) uint64, err"""
+        if program == 0:
+            msg, r, s, pkx, pky = [np.ascontiguousarray(a, np.uint8) for a in inputs]
+        else:
+            pkx, pky, msg = [np.ascontiguousarray(a, np.uint8) for a in inputs]
+            r = s = None
+        cols, aux = np.ascontiguousarray(cols, np.uint64), np.ascontiguousarray(aux, np.uint64)
+        n = cols.shape[1]
+        k = 249385 if program == 0 else 194361
+        ux, err = _z(k, n), np.zeros(n, np.uint8)
+        got = self.L.emu_ux(C.c_int(program), _p(msg), _p(r) if r is not None else None, _p(s) if s is not None else None, _p(pkx),
+                            _p(pky), _p(cols), C.c_size_t(n), _p(aux), C.c_size_t(n), _p(ux), C.c_size_t(n), C.c_size_t(n), _p(err))
+        assert got == k
+        return ux, err
 
     def mul(self, field, x, y):
         x, y = np.ascontiguousarray(x, np.uint64), np.ascontiguousarray(y, np.uint64)

@@ -308,6 +308,32 @@ long emu_aux_compact(int program, const uint8_t* pky, const uint32_t* narrow, si
     }
     return bad;
 }
+// constraint-block columns from finished matrices (ux.hpp: the body k_ux runs); inputs by INPUT_* slot
+long emu_ux(int program, const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx, const uint8_t* pky,
+            const uint64_t* cols, size_t ld, const uint64_t* aux, size_t ald, uint64_t* ux, size_t uld, size_t n, uint8_t* err) {
+    host::ScheduleBuilder sb;
+    if (program == 0)
+        sb.verify_secp256k1_message_circuit();
+    else
+        sb.glv_mul_circuit();
+    U256 cv[NUM_CONSTV];
+    for (u32 id = 0; id < NUM_CONSTV; id++) cv[id] = host::ScheduleBuilder::const_value(id);
+    std::vector<u32> err32(n);
+    UxArgs A{};
+    A.cols = cols; A.ld = ld; A.aux = aux; A.ald = ald; A.ux = ux; A.uld = uld; A.n = n;
+    A.in[INPUT_PY] = pky; A.in[INPUT_PX] = pkx; A.in[INPUT_MSG] = msg; A.in[INPUT_R] = r ? r : msg; A.in[INPUT_S] = s ? s : msg;
+    A.consts = cv; A.items = sb.ux_items.data(); A.err = err32.data();
+    for (int item = 0; item < (int)sb.ux_items.size(); item++) {
+#pragma omp parallel for
+        for (long long i = 0; i < (long long)n; i++) body_ux<Emit>(A, item, (size_t)i);
+    }
+    long bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        err[i] = (uint8_t)err32[i];
+        bad += err32[i] != 0;
+    }
+    return (long)sb.num_ux_cols + 0 * bad;
+}
 long emu_aux_num_cols(int program) {
     host::ScheduleBuilder sb;
     if (program == 0)

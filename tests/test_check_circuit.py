@@ -109,3 +109,52 @@ def test_wrong_inputs_fail_the_replay():
         wrong[k] ^= 1 << 17
         with pytest.raises(CC.ConstraintViolation):
             CC.check_verify(cols, *wrong)
+
+
+@pytest.mark.parametrize("program", [0, 1])
+def test_library_wiring_equals_the_replayed_gadget_wiring(program):
+    """include/p2e.h p2e_schedule_wiring (C++ ScheduleBuilder: where every generator's operands live) against the
+    operand sources the constraint replay records while it walks the reference's gadgets: same source for every
+    operand of all 3 555 generators, same limb counts (constants keep convert_base's count, quirk Q5), same
+    range_check flags.  This is the table the 8(f) rank 2 / rank 3 kernels are driven by."""
+    import plonky2_ecdsa_amd as p2e
+    if program == 0:
+        cols, ins, aux, _ = _golden(0)
+        c = CC.check_verify(cols, *ins, aux=aux)
+    else:
+        g = np.load(pc.GOLD + "/glv_mul_golden.npz")
+        c = CC.check_glv_mul(g["cols"][:, 0], *CC.unpack_inputs([g["inputs"][:, k, :] for k in range(3)], 0))
+    wiring = p2e.schedule_wiring(program)
+    consts = {cid: p2e.wiring_const(cid) for cid in range(10)}
+    slot = {"pky": 0, "pkx": 1, "msg": 2, "k": 2, "r": 3, "s": 4}
+    assert len(wiring) == len(c.gens)
+    n_rc = 0
+    for (kind, field, c0, nc, label, operands), (w_ops, w_rc) in zip(c.gens, wiring):
+        assert len(operands) == len(w_ops), (label, kind)
+        for limbs, (src, nl) in zip(operands, w_ops):
+            limbs = list(limbs)
+            assert len(limbs) == nl, (label, kind, limbs, nl)
+            if nl == 0:
+                assert src == p2e.SRC_CONST | 6                     # the zero constant: no limbs
+                continue
+            first = limbs[0]
+            if first[0] == "col":
+                assert src == first[1] and [s for s in limbs] == [("col", first[1] + k) for k in range(nl)]
+            elif first[0] == "aux":
+                assert src == p2e.SRC_AUX | first[1] and limbs == [("aux", first[1] + k) for k in range(nl)]
+            elif first[0] == "in":
+                assert src == p2e.SRC_INPUT | slot[first[1]] and limbs == [("in", first[1], k) for k in range(nl)]
+            else:
+                assert src & p2e.SRC_CONST and (src & 0xFFFF) in consts
+                value, cnl = consts[src & 0xFFFF]
+                assert cnl == nl and [v for _, v in limbs] == R.const_limbs(value)
+        n_rc += w_rc
+    # range_check flags: replay them from the reference's call sites through the U29 block sizes the replay recorded
+    # (a range-checked gadget has exactly one more value, the cmp_biguint result, in its constraint block)
+    base = {"add": 45, "sub": 47, "inv": 434, "mul": 0, "glv": None}
+    for (kind, field, c0, nc, label, operands), (w_ops, w_rc), (u0, un, ulabel) in zip(
+            [g for g in c.gens if g[0] != "glv"], [w for g, w in zip(c.gens, wiring) if g[0] != "glv"], c.ux_ops):
+        if kind in base:
+            # operands shorter than 9 limbs do not change the count: add_biguint runs over max(len) limbs
+            assert un - base[kind] == int(w_rc), (label, kind, un, w_rc)
+    assert n_rc > 0

@@ -577,3 +577,58 @@ def test_failed_calls_clean_up_and_the_context_survives():
     assert bad == 0 and int(valid.sum()) == n and np.array_equal(got[:, :4].cpu().numpy().view(np.uint64), want)
     # the caller's current device is left alone (single-GPU box: still 0) and the library reports a sane status
     assert torch.cuda.current_device() == 0 and dctx.sync() == 0
+
+
+@pytest.mark.parametrize("program", [0, 1])
+def test_constraint_block_columns_match_the_replay_model(program):
+    """SURVEY 8(f) rank 2 (p2e_ux_witness_batch): the U29-gate values of every constraint block, derived on the GPU from
+    its own witness + aux matrices through the wiring table, against the constraint replay's model (which recomputes
+    them from the reference's gadgets while checking every constraint on the same GPU witness).  n = 300: a full
+    workgroup of paired stores + a ragged tail; u32 and u64 outputs, padded strides."""
+    import torch
+    import check_circuit as CC
+    import plonky2_ecdsa_amd as p2e
+    n = 300
+    sigs = p2e.synth_signatures(seed=3030, n=n)
+    ctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    if program == 0:
+        cols, _e, valid, bad = ctx.ecdsa_verify_witness_batch(*dev)
+        inputs, ks = dev, None
+    else:
+        rng = R.SplitMix64(3031)
+        ks = [rng.below(R.N) for _ in range(n)]
+        kd = torch.from_numpy(oracle_c.pack256(ks)).cuda()
+        cols, _e, valid, bad = ctx.glv_mul_witness_batch(dev[3], dev[4], kd)
+        inputs = [dev[3], dev[4], kd]
+    aux, _ae, abad = ctx.aux_witness_batch(program, dev[4], cols)
+    k = p2e.ux_num_cols(program)
+    big32 = torch.full((k, n + 6), -1, dtype=torch.int32, device="cuda")
+    ux32, e32, b32 = ctx.ux_witness_batch(program, inputs, cols, aux, ux=big32[:, :n])
+    ux64, e64, b64 = ctx.ux_witness_batch(program, inputs, cols, aux, u32=False)
+    torch.cuda.synchronize()
+    assert bad == 0 and abad == 0 and b32 == 0 and b64 == 0 and ux64.shape == (k, n)
+    assert bool((big32[:, n:] == -1).all())                                 # padding untouched
+    h32 = ux32.cpu().numpy().view(np.uint32)
+    assert np.array_equal(h32.astype(np.uint64), ux64.cpu().numpy().view(np.uint64)) and int(h32.max()) < 1 << 29
+    host, haux = cols.cpu().numpy().view(np.uint64), aux.cpu().numpy().view(np.uint64)
+    for i in (0, 255, 256, 299):
+        if program == 0:
+            c = CC.check_verify(host[:, i], *CC.unpack_inputs(sigs, i), aux=haux[:, i], ux=h32[:, i])
+        else:
+            px, py = CC.unpack_inputs(sigs[3:5], i)
+            c = CC.check_glv_mul(host[:, i], px, py, ks[i], aux=haux[:, i], ux=h32[:, i])
+        assert len(c.ux) == k
+    # host-pointer (staged) path on a tiny batch, u32
+    hctx = p2e.Context(device=0, host_pointers=True)
+    sl = [a[:3] for a in sigs]
+    if program == 0:
+        hc, _, _, _ = hctx.ecdsa_verify_witness_batch(*sl)
+        hin = sl
+    else:
+        hk = oracle_c.pack256(ks[:3])
+        hc, _, _, _ = hctx.glv_mul_witness_batch(sl[3], sl[4], hk)
+        hin = [sl[3], sl[4], hk]
+    ha, _, _ = hctx.aux_witness_batch(program, sl[4], hc)
+    hu, he, hb = hctx.ux_witness_batch(program, hin, hc, ha)
+    assert hb == 0 and np.array_equal(np.asarray(hu), h32[:, :3])

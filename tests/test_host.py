@@ -343,3 +343,49 @@ def test_binary_gcd_inversion_round_bound():
     L.emu_bingcd_selfcheck.restype = C.c_long
     for field in (0, 1):
         assert L.emu_bingcd_selfcheck(C.c_int(field), C.c_ulonglong(99 + field), C.c_size_t(200000)) == 0
+
+
+def _ux_digest(v):
+    import hashlib
+    return hashlib.sha256(np.asarray(v, dtype="<u4").tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("program", [0, 1])
+def test_constraint_block_columns_match_the_replay_model_and_the_golden_digests(program):
+    """SURVEY 8(f) rank 2 (csrc/ux.hpp, the body k_ux runs, compiled for the CPU): the values the U29 gates hand back
+    inside every add / sub / add_many / inv constraint block and range check, derived from the golden witness and aux
+    matrices through the schedule's wiring table, against oracle/check_circuit.py's model -- which produces them as a
+    by-product of replaying the reference's constraints on the same witness -- and against the committed digests."""
+    import check_circuit as CC
+    import json
+    dig = json.load(open(os.path.join(pc.GOLD, "ux_digest.json")))["verify" if program == 0 else "glv_mul"]
+    if program == 0:
+        cols, inputs, valid = pc.load_verify_golden()
+        aux = np.load(os.path.join(pc.GOLD, "aux_golden.npz"))["verify"]
+        args = [np.ascontiguousarray(inputs[:, k, :]) for k in range(5)]
+    else:
+        g = np.load(os.path.join(pc.GOLD, "glv_mul_golden.npz"))
+        cols, inputs, valid = g["cols"], g["inputs"], np.ones(g["cols"].shape[1], np.uint8)
+        aux = np.load(os.path.join(pc.GOLD, "aux_golden.npz"))["glv_mul"]
+        args = [np.ascontiguousarray(inputs[:, k, :]) for k in range(3)]
+    ux, err = EmuBackend().ux(program, args, cols, aux)
+    assert not err.any() and ux.shape[0] == p2e.ux_num_cols(program) == (p2e.VERIFY_UX_COLS if program == 0 else p2e.GLV_MUL_UX_COLS)
+    assert int(ux.max()) < 1 << 29
+    for i in range(cols.shape[1]):
+        if not valid[i]:
+            continue
+        ins = CC.unpack_inputs([inputs[:, k, :] for k in range(inputs.shape[1])], i)
+        c = (CC.check_verify if program == 0 else CC.check_glv_mul)(cols[:, i], *ins)
+        assert np.array_equal(ux[:, i], np.array(c.ux, dtype=np.uint64))
+        assert _ux_digest(c.ux) == dig[i]["sha256"] and len(c.ux) == dig[i]["len"]
+        # the library's per-generator block map is the replay's
+        blocks = [(u0, un) for (u0, un, _l) in c.ux_ops]
+        lib = [b for (b, g) in zip(p2e.ux_describe(program), c.gens) if g[0] != "glv"]
+        assert lib == blocks
+    # feeding the derived vector back: the replay accepts it, and rejects a corrupted one
+    c = (CC.check_verify if program == 0 else CC.check_glv_mul)(cols[:, 0], *CC.unpack_inputs([inputs[:, k, :] for k in range(inputs.shape[1])], 0),
+                                                                 ux=ux[:, 0])
+    bad = ux[:, 0].copy()
+    bad[12345] ^= np.uint64(1)
+    with pytest.raises(CC.ConstraintViolation):
+        (CC.check_verify if program == 0 else CC.check_glv_mul)(cols[:, 0], *CC.unpack_inputs([inputs[:, k, :] for k in range(inputs.shape[1])], 0), ux=bad)
