@@ -195,6 +195,33 @@ typedef struct p2e_ux_desc {
 long p2e_ux_describe(int program, p2e_ux_desc *out, size_t cap);
 long p2e_ux_num_cols(int program);
 
+/* ---- wire-matrix assembly -------------------------------------------------- */
+/* plonky2's prover consumes one matrix per proof, wire_values[num_wires][degree] (PartitionWitness::full_witness,
+ * [upstream-from-memory]); a generator's targets are Target::wire(row, column) of the gate rows the builder placed
+ * (gates/mul_nonnative.rs:208-226) or virtual targets.  The placement belongs to the circuit build on the Rust side,
+ * so it is an INPUT here: a map from library columns to wire-matrix positions, built once per circuit from the
+ * targets the gadgets returned.  One entry copies one value; the same source may feed
+ * several positions (copy constraints: the x / y wires of a MulNonnativeGate row repeat the operand's limbs).
+ *   src = P2E_WIRE_SRC_COLS | c, P2E_WIRE_SRC_AUX | c or P2E_WIRE_SRC_UX | c   (column c of that matrix)
+ *   dst = wire * degree + row        (element index inside one signature's wire matrix)
+ * p2e_wire_map_create sorts a copy by dst (coalesced scatter) and keeps it on the device; entries must be in range
+ * (dst < num_wires * degree) and no two entries may share a dst.
+ * p2e_assemble_wires: wires[i * wire_stride + dst] = value of signature i, for every map entry; positions no entry
+ * names are left as they are (zero-fill once, re-use the buffer).  wire_stride >= num_wires * degree elements.
+ * A matrix whose entries the map does not use may be NULL.  ux is the u64 or u32 matrix of p2e_ux_witness_batch. */
+#define P2E_WIRE_SRC_COLS 0x00000000u
+#define P2E_WIRE_SRC_AUX 0x40000000u
+#define P2E_WIRE_SRC_UX 0x80000000u
+typedef struct p2e_wire_map_entry {
+    uint32_t src, dst;
+} p2e_wire_map_entry;
+typedef struct p2e_wire_map p2e_wire_map;
+int p2e_wire_map_create(p2e_ctx *ctx, int program, const p2e_wire_map_entry *entries, size_t count, uint32_t num_wires,
+                        uint32_t degree, p2e_wire_map **out);
+void p2e_wire_map_destroy(p2e_ctx *ctx, p2e_wire_map *map);
+long p2e_assemble_wires(p2e_ctx *ctx, const p2e_wire_map *map, const uint64_t *cols, size_t ld, const uint64_t *aux,
+                        size_t ld_aux, const void *ux, int ux_u32, size_t ld_ux, uint64_t *wires, size_t wire_stride, size_t n);
+
 /* ---- layout helper --------------------------------------------------------------------------------- */
 /* cols[ncols][ld] (column-major over the batch) -> rows[n][row_ld], one contiguous witness per signature:
  * what a per-signature PartialWitness fill (pw.set_biguint_target ... gadgets/biguint.rs:454-463 per target,

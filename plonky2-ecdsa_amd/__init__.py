@@ -50,6 +50,7 @@ EXPORTS = (
     "p2e_add_many_witness_batch", "p2e_inv_witness_batch", "p2e_glv_decompose_batch", "p2e_limb_split",
     "p2e_limb_pack", "p2e_ecdsa_verify_witness_batch", "p2e_glv_mul_witness_batch", "p2e_columns_to_rows",
     "p2e_schedule_describe", "p2e_schedule_wiring", "p2e_wiring_const", "p2e_ux_witness_batch", "p2e_ux_describe", "p2e_ux_num_cols",
+    "p2e_wire_map_create", "p2e_wire_map_destroy", "p2e_assemble_wires",
     "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
     "p2e_compact_layout", "p2e_columns_compact", "p2e_ecdsa_verify_witness_compact_batch",
     "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch", "p2e_compact_to_rows", "p2e_ecdsa_verify_batch", "p2e_biguint_div_rem_batch",
@@ -251,6 +252,18 @@ def synth_signatures(seed: int, n: int, first: int = 0):
     if rc:
         raise P2EError("p2e_synth_signatures failed")
     return out
+
+
+class _WireMap:
+    def __init__(self, ctx, h, program, num_wires, degree, count):
+        self._ctx, self._h, self.program, self.num_wires, self.degree, self.count = ctx, h, program, num_wires, degree, count
+
+    def close(self):
+        if self._h and getattr(self._ctx, "_h", None):
+            self._ctx._L.p2e_wire_map_destroy(self._ctx._h, self._h)
+        self._h = None
+
+    __del__ = close
 
 
 class Context:
@@ -497,6 +510,42 @@ class Context:
                                                        _ptr(cols), C.c_size_t(ld), _ptr(aux), C.c_size_t(ld_aux), _ptr(ux),
                                                        C.c_int(1 if u32 else 0), C.c_size_t(ld_ux), C.c_size_t(n), _ptr(err)))
         return ux, err, bad
+
+    # ---- wire-matrix assembly --------------------------------------------------
+    def wire_map(self, program, src, dst, num_wires, degree):
+        """Upload a column -> (wire, row) map (include/p2e.h p2e_wire_map_create); returns an opaque handle for
+        assemble_wires.  src / dst: uint32 arrays (plonky2_ecdsa_amd.wiremap has a synthetic generator)."""
+        src, dst = np.ascontiguousarray(src, np.uint32), np.ascontiguousarray(dst, np.uint32)
+        ent = np.empty((len(src), 2), dtype=np.uint32)
+        ent[:, 0], ent[:, 1] = src, dst
+        h = C.c_void_p()
+        rc = self._L.p2e_wire_map_create(self._h, C.c_int(program), _ptr(ent), C.c_size_t(len(src)), C.c_uint32(num_wires),
+                                         C.c_uint32(degree), C.byref(h))
+        if rc != 0:
+            raise P2EError(f"p2e_wire_map_create failed ({rc}): {self._L.p2e_last_error().decode()}")
+        return _WireMap(self, h, program, num_wires, degree, len(src))
+
+    def assemble_wires(self, wmap, cols=None, aux=None, ux=None, wires=None, n=None):
+        """wires[i, wire * degree + row] = the mapped value of signature i: (n, num_wires * degree) int64, one plonky2 wire
+        matrix per signature (zero where the map names nothing, when allocated here)."""
+        ref = cols if cols is not None else (aux if aux is not None else ux)
+        n = n if n is not None else self._shape(ref)[1]
+        cells = wmap.num_wires * wmap.degree
+        if wires is None:
+            if self.host_pointers:
+                wires = np.zeros((n, cells), dtype=np.uint64)
+            else:
+                import torch
+                wires = torch.zeros((n, cells), dtype=torch.int64, device=f"cuda:{self.device}")
+        u32 = 0
+        if ux is not None:
+            u32 = int((ux.dtype == np.uint32) if isinstance(ux, np.ndarray) else (ux.element_size() == 4))
+        self._L.p2e_assemble_wires.restype = C.c_long
+        self._check(self._L.p2e_assemble_wires(self._h, wmap._h, _ptr(cols), C.c_size_t(_ld(cols) if cols is not None else 0),
+                                               _ptr(aux), C.c_size_t(_ld(aux) if aux is not None else 0), _ptr(ux), C.c_int(u32),
+                                               C.c_size_t(_ld(ux) if ux is not None else 0), _ptr(wires),
+                                               C.c_size_t(_ld(wires)), C.c_size_t(n)))
+        return wires
 
     def columns_compact(self, program, cols, n=None, ld=None, narrow=None, wide=None, err=None, ld_narrow=None, ld_wide=None):
         """Repack a finished witness matrix for transfers: (narrow u32 (num_narrow, n), wide u64 (num_wide, n), err, bad).

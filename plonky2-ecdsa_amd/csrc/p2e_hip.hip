@@ -2,6 +2,7 @@
 // One process drives one GPU; every entry point enqueues on the context's stream.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -278,6 +279,53 @@ __global__ __launch_bounds__(BS) void k_transpose(const T* __restrict__ cols, si
     }
 }
 
+// Wire-matrix assembly (p2e_assemble_wires): out[sig][dst(e)] = M_src(e)[col(e)][sig] for the entries e of a map
+// sorted by dst.  A tile of 64 entries x 64 signatures goes through LDS like k_transpose: the gather side reads 64
+// consecutive signatures of one column per row (512 B runs), the scatter side writes, per signature, 64 entries whose
+// destinations are consecutive wherever the map is (runs of rows of one wire).
+struct AssembleArgs {
+    const u64* cols;
+    size_t ld;
+    const u64* aux;
+    size_t ald;
+    const void* ux;
+    size_t uld;
+    int ux_u32;
+    const u32* src;   // [count]
+    const u32* dst;   // [count], ascending
+    size_t count;
+    u64* wires;
+    size_t stride, n;
+};
+__global__ __launch_bounds__(BS) void k_assemble(AssembleArgs A) {
+    __shared__ u64 tile[64][65];
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t s0 = (size_t)blockIdx.x * 64, e0 = (size_t)blockIdx.y * 64;
+#pragma unroll 4
+    for (unsigned r = w; r < 64; r += 4) {   // entry e0 + r, signatures s0 .. s0 + 63
+        const size_t e = e0 + r, sg = s0 + lane;
+        if (e < A.count && sg < A.n) {
+            const u32 s = A.src[e], c = s & 0x3FFFFFFFu;
+            u64 v;
+            if ((s >> 30) == 0)
+                v = A.cols[(size_t)c * A.ld + sg];
+            else if ((s >> 30) == 1)
+                v = A.aux[(size_t)c * A.ald + sg];
+            else
+                v = A.ux_u32 ? (u64) static_cast<const u32*>(A.ux)[(size_t)c * A.uld + sg] : static_cast<const u64*>(A.ux)[(size_t)c * A.uld + sg];
+            tile[r][lane] = v;
+        }
+    }
+    __syncthreads();
+    const size_t e = e0 + lane;
+    const u32 d = e < A.count ? A.dst[e] : 0u;
+#pragma unroll 4
+    for (unsigned r = w; r < 64; r += 4) {   // signature s0 + r, entries e0 .. e0 + 63
+        const size_t sg = s0 + r;
+        if (sg < A.n && e < A.count) A.wires[sg * A.stride + d] = tile[lane][r];
+    }
+}
+
 // Compact container for transfers (p2e_columns_compact): every column whose values are < 2^32 by construction
 // (29-bit limbs, overflow words, flags: 57 % of the columns) is repacked as u32, the check_sum / carry columns of
 // the mul generators stay u64.  map[c] = index of column c in its matrix | P2E_COMPACT_WIDE.  One lane moves two
@@ -421,6 +469,7 @@ struct p2e_ctx {
     // small-batch plan: dynamic LDS bytes requested by the expansion kernels (they do not use it): caps how many of
     // their workgroups share a CU, so that the register file keeps room for the chain waves queued behind them
     unsigned expand_lds_small = 160000;
+    unsigned expand_lds = 0;   // the same knob for the large-batch plan
     Aff* d_cpts = nullptr;
     Aff* d_fbtab = nullptr;
     U256* d_constv = nullptr;   // circuit constants by id (AUX_SRC_CONST | id), for the constraint-block pass
@@ -573,6 +622,7 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     if (const char* env = getenv("P2E_RUNS_MIN_N")) c->runs_min_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_QUAD_MAX_N")) c->quad_max_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_EXPAND_LDS_SMALL")) c->expand_lds_small = (unsigned)strtoul(env, nullptr, 10);
+    if (const char* env = getenv("P2E_EXPAND_LDS")) c->expand_lds = (unsigned)strtoul(env, nullptr, 10);
     if (const char* env = getenv("P2E_BINV_SPLIT_LOG2")) {
         int v = atoi(env);
         if (v >= 0 && v <= 4) c->binv_split_log2 = v;
@@ -1254,7 +1304,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         }
     c->n_expand = 0;
     bool used_c2 = false;
-    emit_lds = quad ? c->expand_lds_small : 0;
+    emit_lds = quad ? c->expand_lds_small : c->expand_lds;
     for (int q = 0; q < ns; q++) {
         const int k = order[q];
         const Seg& sg = segs[k];
@@ -1475,6 +1525,97 @@ extern "C" long p2e_aux_witness_compact_batch(p2e_ctx* c, int program, const uin
     }
     if (n == 0) return 0;
     return run_aux(c, program, pky32, nullptr, 0, narrow, ld_narrow, aux32, true, ld_aux, n, err);
+}
+
+struct p2e_wire_map {
+    int program = 0;
+    u32* d_src = nullptr;
+    u32* d_dst = nullptr;
+    size_t count = 0;
+    u32 num_wires = 0, degree = 0;
+    bool uses[3] = {false, false, false};
+};
+extern "C" int p2e_wire_map_create(p2e_ctx* c, int program, const p2e_wire_map_entry* entries, size_t count, uint32_t num_wires,
+                                   uint32_t degree, p2e_wire_map** out) {
+    if (!c || !out || program < 0 || program > 1 || (!entries && count) || !num_wires || !degree) return P2E_E_INVALID;
+    const DeviceProgram& HP = host_program(program);
+    const u64 cells = (u64)num_wires * degree;
+    const u32 limit[3] = {(u32)HP.prog.num_cols, HP.aux_tab.num_aux_cols, HP.num_ux_cols};
+    std::vector<p2e_wire_map_entry> v(entries, entries + count);
+    std::stable_sort(v.begin(), v.end(), [](const p2e_wire_map_entry& a, const p2e_wire_map_entry& b) { return a.dst < b.dst; });
+    auto m = new p2e_wire_map();
+    for (size_t k = 0; k < count; k++) {
+        const u32 kind = v[k].src >> 30, col = v[k].src & 0x3FFFFFFFu;
+        if (kind > 2 || col >= limit[kind] || v[k].dst >= cells || (k && v[k].dst == v[k - 1].dst)) {
+            set_error(kind > 2 || col >= limit[kind < 3 ? kind : 0] ? "wire map: source column out of range"
+                      : v[k].dst >= cells                          ? "wire map: destination outside num_wires * degree"
+                                                                   : "wire map: two entries share a destination");
+            delete m;
+            return P2E_E_INVALID;
+        }
+        m->uses[kind] = true;
+    }
+    std::vector<u32> src(count), dst(count);
+    for (size_t k = 0; k < count; k++) {
+        src[k] = v[k].src;
+        dst[k] = v[k].dst;
+    }
+    DeviceGuard guard(c->device);
+    m->program = program;
+    m->count = count;
+    m->num_wires = num_wires;
+    m->degree = degree;
+    if (hipMalloc(&m->d_src, sizeof(u32) * (count ? count : 1)) != hipSuccess || hipMalloc(&m->d_dst, sizeof(u32) * (count ? count : 1)) != hipSuccess ||
+        hipMemcpy(m->d_src, src.data(), sizeof(u32) * count, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_dst, dst.data(), sizeof(u32) * count, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(m->d_src);
+        (void)hipFree(m->d_dst);
+        delete m;
+        set_error("wire map: device allocation failed");
+        return P2E_E_NOMEM;
+    }
+    *out = m;
+    return 0;
+}
+extern "C" void p2e_wire_map_destroy(p2e_ctx* c, p2e_wire_map* m) {
+    if (!m) return;
+    if (c) {
+        DeviceGuard guard(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(m->d_src);
+        (void)hipFree(m->d_dst);
+    }
+    delete m;
+}
+extern "C" long p2e_assemble_wires(p2e_ctx* c, const p2e_wire_map* m, const uint64_t* cols, size_t ld, const uint64_t* aux,
+                                   size_t ld_aux, const void* ux, int ux_u32, size_t ld_ux, uint64_t* wires, size_t wire_stride, size_t n) {
+    if (!c || !m || !wires || wire_stride < (size_t)m->num_wires * m->degree || (m->uses[0] && (!cols || ld < n)) ||
+        (m->uses[1] && (!aux || ld_aux < n)) || (m->uses[2] && (!ux || ld_ux < n))) {
+        set_error("p2e_assemble_wires: null matrix the map reads, ld < n, or wire_stride < num_wires * degree");
+        return P2E_E_INVALID;
+    }
+    if (n == 0 || m->count == 0) return 0;
+    const DeviceProgram& DP = c->progs[m->program];
+    Staged S(c);
+    if (cols) cols = S.in(cols, (size_t)DP.prog.num_cols * ld * 8);
+    if (aux) aux = S.in(aux, (size_t)DP.aux_tab.num_aux_cols * ld_aux * 8);
+    if (ux) ux = S.in((const char*)ux, (size_t)DP.num_ux_cols * ld_ux * (ux_u32 ? 4 : 8));
+    uint64_t* const host_wires = wires;
+    void* d_stage = nullptr;
+    if (S.host) {   // in-out buffer: positions no entry names keep the caller's values
+        d_stage = S.stage(n * wire_stride * 8);
+        if (d_stage && hipMemcpyAsync(d_stage, host_wires, n * wire_stride * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) S.rc = P2E_E_HIP;
+        if (d_stage) S.outs.push_back({host_wires, d_stage, n * wire_stride * 8});
+        wires = (uint64_t*)d_stage;
+    }
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    AssembleArgs A{cols, ld, aux, ld_aux, ux, ld_ux, ux_u32, m->d_src, m->d_dst, m->count, wires, wire_stride, n};
+    dim3 grid((unsigned)((n + 63) / 64), (unsigned)((m->count + 63) / 64));
+    hipLaunchKernelGGL(k_assemble, grid, dim3(BS), 0, c->stream, A);
+    c->have_phases = false;
+    return S.done(finish_call(c));
 }
 
 extern "C" long p2e_ux_witness_batch(p2e_ctx* c, int program, const uint8_t* msg32, const uint8_t* r32, const uint8_t* s32,

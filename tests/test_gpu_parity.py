@@ -632,3 +632,67 @@ def test_constraint_block_columns_match_the_replay_model(program):
     ha, _, _ = hctx.aux_witness_batch(program, sl[4], hc)
     hu, he, hb = hctx.ux_witness_batch(program, hin, hc, ha)
     assert hb == 0 and np.array_equal(np.asarray(hu), h32[:, :3])
+
+
+def test_assemble_wires_against_numpy():
+    """SURVEY 8(f) rank 3 (p2e_assemble_wires): every column of the three matrices scattered into one plonky2 wire matrix
+    per signature through a host-supplied (column -> wire * degree + row) map -- here the synthetic standard_ecc_config
+    placement of plonky2_ecdsa_amd.wiremap (378 878 entries, 136 wires x 8192 rows, mul-gate rows with repeated sources)
+    and a random permutation map -- against the same scatter in numpy.  n = 96: one full tile of signatures + a ragged one."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    from plonky2_ecdsa_amd.wiremap import synthetic_wire_map, WIRE_SRC_AUX, WIRE_SRC_UX
+    n = 96
+    sigs = p2e.synth_signatures(seed=888, n=n)
+    ctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    cols, _e, valid, bad = ctx.ecdsa_verify_witness_batch(*dev)
+    aux, _ae, abad = ctx.aux_witness_batch(0, dev[4], cols)
+    ux, _ue, ubad = ctx.ux_witness_batch(0, dev, cols, aux)                   # u32
+    assert bad == abad == ubad == 0 and int(valid.sum()) == n
+    hc, ha, hu = cols.cpu().numpy().view(np.uint64), aux.cpu().numpy().view(np.uint64), ux.cpu().numpy().view(np.uint32)
+
+    def reference(src, dst, cells):
+        out = np.zeros((n, cells), dtype=np.uint64)
+        kind, col = src >> 30, src & 0x3FFFFFFF
+        for k, m in ((0, hc), (1, ha), (2, hu)):
+            sel = kind == k
+            out[:, dst[sel]] = m[col[sel]].T
+        return out
+
+    src, dst, nw, deg = synthetic_wire_map(0)
+    assert nw == 136 and len(src) == 378878
+    wm = ctx.wire_map(0, src, dst, nw, deg)
+    wires = ctx.assemble_wires(wm, cols, aux, ux)
+    torch.cuda.synchronize()
+    assert np.array_equal(wires.cpu().numpy().view(np.uint64), reference(src, dst, nw * deg))
+    # untouched cells keep the caller's values; a random map (sources repeated, destinations scattered); u64 ux matrix
+    rng = np.random.default_rng(5)
+    cells = 1 << 18
+    cnt = 100_001
+    rsrc = np.concatenate([rng.integers(0, p2e.VERIFY_COLS, cnt // 3), WIRE_SRC_AUX | rng.integers(0, p2e.VERIFY_AUX_COLS, cnt // 3),
+                           WIRE_SRC_UX | rng.integers(0, p2e.VERIFY_UX_COLS, cnt - 2 * (cnt // 3))]).astype(np.uint32)
+    rdst = rng.permutation(cells)[:cnt].astype(np.uint32)
+    wm2 = ctx.wire_map(0, rsrc, rdst, 64, cells // 64)
+    ux64, _, _ = ctx.ux_witness_batch(0, dev, cols, aux, u32=False)
+    pre = torch.full((n, cells + 5), -7, dtype=torch.int64, device="cuda")
+    ctx.assemble_wires(wm2, cols, aux, ux64, wires=pre[:, :cells])
+    torch.cuda.synchronize()
+    got = pre.cpu().numpy()
+    want = reference(rsrc, rdst, cells).view(np.int64)
+    named = np.zeros(cells, dtype=bool)
+    named[rdst] = True
+    assert np.array_equal(got[:, :cells][:, named], want[:, named])
+    assert (got[:, :cells][:, ~named] == -7).all() and (got[:, cells:] == -7).all()
+    # map validation: duplicate destination, destination / source out of range
+    for s_, d_ in (([1, 2], [5, 5]), ([1], [64 * 16]), ([p2e.VERIFY_COLS], [0]), ([WIRE_SRC_UX | p2e.VERIFY_UX_COLS], [0])):
+        with pytest.raises(p2e.P2EError):
+            ctx.wire_map(0, np.array(s_, np.uint32), np.array(d_, np.uint32), 64, 16)
+    # a map that reads only the witness matrix needs no other matrix
+    only = ctx.wire_map(0, np.arange(100, dtype=np.uint32), np.arange(100, dtype=np.uint32)[::-1].copy(), 10, 10)
+    w3 = ctx.assemble_wires(only, cols)
+    assert np.array_equal(w3.cpu().numpy().view(np.uint64)[:, ::-1][:, :100], hc[:100].T)
+    # staged host-pointer path
+    hctx = p2e.Context(device=0, host_pointers=True)
+    hw = hctx.assemble_wires(hctx.wire_map(0, rsrc, rdst, 64, cells // 64), hc[:, :5].copy(), ha[:, :5].copy(), hu[:, :5].copy())
+    assert np.array_equal(np.asarray(hw)[:, named], want[:5][:, named].view(np.uint64))
