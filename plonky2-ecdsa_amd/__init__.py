@@ -28,7 +28,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libp2e_hip.so")
+# P2E_LIB: an alternative build of the same library (A/B experiments under tools/); never set in production
+LIB_PATH = os.environ.get("P2E_LIB") or os.path.join(_HERE, "libp2e_hip.so")
 
 FIELD_BASE = 0    # plonky2 Secp256K1Base
 FIELD_SCALAR = 1  # plonky2 Secp256K1Scalar

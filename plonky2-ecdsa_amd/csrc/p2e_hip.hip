@@ -56,7 +56,24 @@ __global__ __launch_bounds__(BS) void k_chains(Program G, Buffers B, int lo, int
     // earlier pieces: win every issue arbitration against them
     __builtin_amdgcn_s_setprio(3);
     size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+#ifdef P2E_LDS_FBTAB
+    // experiment: the fixed-base table rows of this piece's windows staged in LDS
+    constexpr int MAXW = 36;
+    __shared__ Aff s_fb[MAXW * 16];
+    const OpDesc first = load_op(B.ops, lo);
+    const bool fb = first.kind != OP_DBL && ref_kind(first.ref2) == R_FBTAB && hi - lo <= MAXW;
+    const u32 w0 = ref_id(first.ref2);
+    if (fb) {
+        const int nwin = (hi - lo) < (int)(FB_WINDOWS - w0) ? (hi - lo) : (int)(FB_WINDOWS - w0);
+        const u32* src = reinterpret_cast<const u32*>(B.fbtab + (size_t)w0 * 16);
+        u32* dst = reinterpret_cast<u32*>(s_fb);
+        for (int k = threadIdx.x; k < nwin * 16 * 16; k += BS) dst[k] = src[k];
+    }
+    __syncthreads();
+    if (i < B.n) body_chain_range(G, B, i, lo, hi, table_affine != 0, continue_prefix != 0, fb ? s_fb : nullptr, w0);
+#else
     if (i < B.n) body_chain_range(G, B, i, lo, hi, table_affine != 0, continue_prefix != 0);
+#endif
 }
 // small batches: four lanes per signature (quad.hpp); the four lanes of a quad are consecutive threads
 __global__ __launch_bounds__(BS) void k_chains_quad(Program G, Buffers B, int lo, int hi, int table_affine, int continue_prefix) {
@@ -86,7 +103,17 @@ __global__ __launch_bounds__(BS) void k_batch_inv(Program G, Buffers B, int lo, 
 template <int MODE>
 __global__ __launch_bounds__(BS) void k_expand(Program G, Buffers B, int lo, size_t first) {
     size_t i = lane_sig<(MODE & 1) != 0>(first);
+#ifdef P2E_LDS_FBTAB
+    // experiment: the 16 table entries of this op's window staged in LDS (one op per workgroup row)
+    __shared__ Aff s_fb[16];
+    const OpDesc op0 = load_op(B.ops, lo + (int)blockIdx.y);
+    const bool fb = op0.kind != OP_DBL && ref_kind(op0.ref2) == R_FBTAB;
+    if (fb) reinterpret_cast<u32*>(s_fb)[threadIdx.x] = reinterpret_cast<const u32*>(B.fbtab + (size_t)ref_id(op0.ref2) * 16)[threadIdx.x];
+    __syncthreads();
+    if ((MODE & 1) || i < B.n) body_expand<typename EmitOf<MODE>::type>(G, B, i, lo + (int)blockIdx.y, fb ? s_fb : nullptr);
+#else
     if ((MODE & 1) || i < B.n) body_expand<typename EmitOf<MODE>::type>(G, B, i, lo + (int)blockIdx.y);
+#endif
 }
 // runs of MSM-loop iterations: run blockIdx.y of the launch covers iterations [it_first + y*R, +R) capped at it_end
 template <int MODE>

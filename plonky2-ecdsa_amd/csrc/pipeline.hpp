@@ -276,8 +276,11 @@ P2E_HD Jac load_jac_src(const Buffers& B, size_t i, uint16_t src, bool z_one) {
     }
     return j;
 }
-P2E_HD Aff load_fbtab(const Buffers& B, size_t i, u32 window, u32& digit) {
+// lds_fb / lds_w0: optional LDS copy of the table rows of windows lds_w0 ... (the north star's "LDS-staged precomputed
+// window tables"; measured against the L2-resident gather in DESIGN.md section 2 -- build with -DP2E_LDS_FBTAB)
+P2E_HD Aff load_fbtab(const Buffers& B, size_t i, u32 window, u32& digit, const Aff* lds_fb = nullptr, u32 lds_w0 = 0) {
     digit = B.dig4[(size_t)window * B.n + i];
+    if (lds_fb) return lds_fb[(window - lds_w0) * 16 + digit];
     return B.fbtab[window * 16 + digit];
 }
 
@@ -301,7 +304,8 @@ P2E_HD Jac jac_select3(bool c1, const Jac& a, bool c2, const Jac& b, const Jac& 
 // table_affine: the MSM window table has already been through phase B (its 23-op piece is inverted before
 // the loop pieces start), so table operands are read in affine form and the 73 window additions are
 // mixed additions (11 multiplications instead of 17).
-P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, bool table_affine, ChainState& st) {
+P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, bool table_affine, ChainState& st,
+                          const Aff* lds_fb = nullptr, u32 lds_w0 = 0) {
     const OpDesc op = load_op(B.ops, t);
     size_t o = (size_t)t * B.n + i;
     JacW res;
@@ -319,7 +323,7 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, b
         uint16_t src2;
         bool z2one = (op.flags & F_Z2ONE) != 0;
         if (ref_kind(op.ref2) == R_FBTAB) {
-            Aff a = load_fbtab(B, i, ref_id(op.ref2), digit);
+            Aff a = load_fbtab(B, i, ref_id(op.ref2), digit, lds_fb, lds_w0);
             p2 = jac_from_aff(a);
             src2 = (uint16_t)(SRC_FB_BIT | (ref_id(op.ref2) * 16 + digit));
         } else {
@@ -377,12 +381,12 @@ P2E_HD U256 range_product(const Buffers& B, size_t i, int last) {
 // ops [lo, hi) of one chain, in order (the range may be a piece of a chain: everything a later piece needs
 // lives in scratch).  continue_prefix: the range extends the inversion batch of the ops just before it.
 P2E_HD void body_chain_range(const Program& G, const Buffers& B, size_t i, int lo, int hi, bool table_affine,
-                             bool continue_prefix) {
+                             bool continue_prefix, const Aff* lds_fb = nullptr, u32 lds_w0 = 0) {
     ChainState st;
     st.out_id = st.p1_id = 0xFFFF;
     st.out.X = st.out.Y = st.out.Z = st.p1.X = st.p1.Y = st.p1.Z = u256_zero();
     st.acc = continue_prefix ? range_product(B, i, lo - 1) : u256_small(1);
-    for (int t = lo; t < hi; t++) body_chain_op(G, B, i, t, table_affine, st);
+    for (int t = lo; t < hi; t++) body_chain_op(G, B, i, t, table_affine, st, lds_fb, lds_w0);
 }
 
 // Ops lo + row + j * rows (j < count) of a piece whose `rows` interleaved sub-chains do not depend on each other.
@@ -482,7 +486,7 @@ P2E_HD Aff wit_curve_double(E& e, const Aff& p, const U256& vinv, uint8_t& err) 
     return r;
 }
 template <class E>
-P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t) {
+P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t, const Aff* lds_fb = nullptr) {
     const OpDesc op = load_op(B.ops, t);
     uint8_t err = 0;
     E e = E::at(B.sink, i, op.col);
@@ -494,7 +498,7 @@ P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t) {
     if (op.kind == OP_DBL) {
         (void)wit_curve_double(e, p1, vinv, err);
     } else {
-        Aff p2 = (s2 & SRC_FB_BIT) ? B.fbtab[s2 & SRC_ID_MASK] : load_aff_src(B, i, (uint16_t)(s2 & (DYN_CONST_BIT | SRC_ID_MASK)));
+        Aff p2 = (s2 & SRC_FB_BIT) ? (lds_fb ? lds_fb[s2 & 15u] : B.fbtab[s2 & SRC_ID_MASK]) : load_aff_src(B, i, (uint16_t)(s2 & (DYN_CONST_BIT | SRC_ID_MASK)));
         const bool sel = (s2 & SRC_SEL_BIT) != 0;
         Aff s = wit_curve_add(e, p1, p2, vinv, err);
         if (op.kind == OP_CADD) {  // gadgets/curve.rs:225-243: sum always computed (Q7), then selected
