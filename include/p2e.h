@@ -27,7 +27,9 @@
  *
  * THREADING  A p2e_ctx is not thread-safe: one context per (host thread, device).  Calls are
  *   synchronous on return unless P2E_CTX_ASYNC is set (then p2e_sync() completes them and returns the
- *   flagged-element count of the last call).
+ *   flagged-element count of the last call).  Every entry point runs on the context's device and restores the
+ *   calling thread's current device before it returns.  A failed call (negative return) has released everything it
+ *   staged and left no work queued on the context's streams; the context stays usable.
  */
 #ifndef P2E_H
 #define P2E_H

@@ -495,6 +495,11 @@ struct p2e_ctx {
     int binv_split_log2 = 2;
     // small-batch plan: dynamic LDS bytes requested by the expansion kernels (they do not use it): caps how many of
     // their workgroups share a CU, so that the register file keeps room for the chain waves queued behind them
+    // small-batch plan: runs per loop piece (front-loaded: the LAST piece's inversion batch and expansion are the
+    // exposed tail of the call, so it is the shortest), 0-terminated; empty = equal pieces.  And the split of the last
+    // piece's inversion batch (latency matters there; the earlier ones only need throughput: fewer inversions).
+    int small_takes[p2e_ctx::MAX_PIECES + 1] = {0};
+    int binv_split_log2_last = 3;
     unsigned expand_lds_small = 160000;
     unsigned expand_lds = 0;   // the same knob for the large-batch plan
     Aff* d_cpts = nullptr;
@@ -650,6 +655,26 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     if (const char* env = getenv("P2E_QUAD_MAX_N")) c->quad_max_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_EXPAND_LDS_SMALL")) c->expand_lds_small = (unsigned)strtoul(env, nullptr, 10);
     if (const char* env = getenv("P2E_EXPAND_LDS")) c->expand_lds = (unsigned)strtoul(env, nullptr, 10);
+    {   // never ask for more dynamic LDS than a workgroup may have on this device (160 KB on gfx950)
+        int max_lds = 0;
+        if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || max_lds <= 0) max_lds = 65536;
+        (void)hipGetLastError();
+        if (c->expand_lds_small > (unsigned)max_lds) c->expand_lds_small = (unsigned)max_lds;
+        if (c->expand_lds > (unsigned)max_lds) c->expand_lds = (unsigned)max_lds;
+    }
+    if (const char* env = getenv("P2E_BINV_SPLIT_LOG2_LAST")) {
+        int v = atoi(env);
+        if (v >= 0 && v <= 4) c->binv_split_log2_last = v;
+    }
+    if (const char* env = getenv("P2E_SMALL_TAKES")) {   // e.g. "24,20,16,9,4": loop iterations per piece (op-by-op expansion: any cut)
+        int k = 0;
+        for (const char* p = env; *p && k < p2e_ctx::MAX_PIECES; k++) {
+            c->small_takes[k] = atoi(p);
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        c->small_takes[k] = 0;
+    }
     if (const char* env = getenv("P2E_BINV_SPLIT_LOG2")) {
         int v = atoi(env);
         if (v >= 0 && v <= 4) c->binv_split_log2 = v;
@@ -1236,11 +1261,19 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         const int nruns = (iters + R - 1) / R;
         int groups = msm_pieces > 1 ? msm_pieces - 1 : 1;
         if (groups > nruns) groups = nruns;
+        // small-batch plan: an explicit list of runs per piece (the list is used while it fits; the last piece takes the rest)
+        int listed = 0;
+        if (quad && c->small_takes[0] > 0) {
+            int sum = 0;
+            while (listed < p2e_ctx::MAX_PIECES - 1 && c->small_takes[listed] > 0 && sum + c->small_takes[listed] < nruns) sum += c->small_takes[listed++];
+            groups = listed + 1;
+        }
         segs[ns++] = Seg{lo0, lb, lb - lo0, c->st_msm, false, lo0, lb, 0, 0};
         int run = 0;
         for (int g = 0; g < groups; g++) {
             int rem = groups - g;
             int take = (nruns - run + rem - 1) / rem;
+            if (listed) take = g < listed ? c->small_takes[g] : nruns - run;
             int it0 = run * R, it1 = (run + take) * R < iters ? (run + take) * R : iters;
             Seg sg{lb + 3 * it0, lb + 3 * it1, lb + 3 * it1 - lo0, c->st_msm, false, 0, 0, it0, it1};
             if (run_iters == 0) {   // no run expansion: op by op
@@ -1261,10 +1294,11 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     c->n_seg = ns;
 
     const unsigned gx4 = (unsigned)((4 * n + BS - 1) / BS);
-    auto launch_binv = [&](hipStream_t st, int lo, int hi, int have_prefix) {
-        if (quad && c->binv_split_log2 > 0)
-            hipLaunchKernelGGL(k_batch_inv_split, dim3((unsigned)(((n << c->binv_split_log2) + BS - 1) / BS)), dim3(BS), 0, st, G, B,
-                               lo, hi, have_prefix, c->binv_split_log2);
+    auto launch_binv = [&](hipStream_t st, int lo, int hi, int have_prefix, bool last_piece = false) {
+        const int sl = last_piece ? c->binv_split_log2_last : c->binv_split_log2;
+        if (quad && sl > 0)
+            hipLaunchKernelGGL(k_batch_inv_split, dim3((unsigned)(((n << sl) + BS - 1) / BS)), dim3(BS), 0, st, G, B, lo, hi,
+                               have_prefix, sl);
         else
             hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, st, G, B, lo, hi, have_prefix);
     };
@@ -1343,7 +1377,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         hipStream_t st_b = (quad && (q & 1)) ? c->st_binv : c->st_fixed;
         if (k != first_msm) {
             HIP_TRY(hipStreamWaitEvent(st_b, c->ev_piece[k], 0));
-            launch_binv(st_b, sg.lo, sg.hi, 1);
+            launch_binv(st_b, sg.lo, sg.hi, 1, k == ns - 1);
             HIP_TRY(hipEventRecord(c->ev_binv[k], st_b));
         }
         // (small-batch plan: phase C alternates between the caller's stream and a second one, so that an expansion
