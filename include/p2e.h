@@ -173,6 +173,21 @@ typedef struct p2e_aux_desc {
 long p2e_aux_describe(int program, p2e_aux_desc *out, size_t cap);
 long p2e_aux_num_cols(int program);
 
+/* Gate-internal values of the built-in gates on the path, the rest of SURVEY.md 8(f) rank 1: what plonky2's own
+ * generators write into wires of their gates beyond the targets the gadgets get back -- per window, in call order,
+ *   is_equal(index, zero) (gadgets/curve_fixed_base.rs:57, gadgets/curve_msm.rs:70): not(equal), the
+ *        EqualityGenerator's inv = index^-1 in Goldilocks (0 for index 0), diff, diff * inv, diff * (diff * inv)
+ *   random_access_curve_points (gadgets/curve_windowed_mul.rs:96-103): per selected limb (9 x, 9 y) the 4 bit
+ *        wires of its RandomAccessGate op's access index, least significant first
+ * (fixed-base windows: is_equal first; MSM digits: random_access first) = 77 values per window, derived from the aux
+ * matrix alone.  gate[P2E_VERIFY_GATE_COLS or P2E_GLV_MUL_GATE_COLS][ld_gate], u64.  [upstream-from-memory: plonky2's
+ * is_equal / EqualityGenerator / RandomAccessGenerator are not in the container; "parity unpinned"] */
+#define P2E_VERIFY_GATE_COLS 10703
+#define P2E_GLV_MUL_GATE_COLS 5621
+long p2e_gate_internal_batch(p2e_ctx *ctx, int program, const uint64_t *aux, size_t ld_aux, uint64_t *gate, size_t ld_gate,
+                             size_t n);
+long p2e_gate_internal_num_cols(int program);
+
 /* ---- constraint-block columns ---------------------------------------------- */
 /* The values of the targets the plonky2_ux U29 gates fill INSIDE the constraint blocks of the non-native gadgets
  * (gadgets/nonnative.rs:262-273 add, :330-351 add_many, :373-386 sub, :518-530 inv, :462-463 mul's range check): what
@@ -204,16 +219,18 @@ long p2e_ux_num_cols(int program);
  * so it is an INPUT here: a map from library columns to wire-matrix positions, built once per circuit from the
  * targets the gadgets returned.  One entry copies one value; the same source may feed
  * several positions (copy constraints: the x / y wires of a MulNonnativeGate row repeat the operand's limbs).
- *   src = P2E_WIRE_SRC_COLS | c, P2E_WIRE_SRC_AUX | c or P2E_WIRE_SRC_UX | c   (column c of that matrix)
+ *   src = P2E_WIRE_SRC_COLS | c, P2E_WIRE_SRC_AUX | c, P2E_WIRE_SRC_UX | c or P2E_WIRE_SRC_GATE | c   (column c of that matrix)
  *   dst = wire * degree + row        (element index inside one signature's wire matrix)
  * p2e_wire_map_create sorts a copy by dst (coalesced scatter) and keeps it on the device; entries must be in range
  * (dst < num_wires * degree) and no two entries may share a dst.
  * p2e_assemble_wires: wires[i * wire_stride + dst] = value of signature i, for every map entry; positions no entry
  * names are left as they are (zero-fill once, re-use the buffer).  wire_stride >= num_wires * degree elements.
- * A matrix whose entries the map does not use may be NULL.  ux is the u64 or u32 matrix of p2e_ux_witness_batch. */
+ * A matrix whose entries the map does not use may be NULL.  ux is the u64 or u32 matrix of p2e_ux_witness_batch, gate
+ * the matrix of p2e_gate_internal_batch. */
 #define P2E_WIRE_SRC_COLS 0x00000000u
 #define P2E_WIRE_SRC_AUX 0x40000000u
 #define P2E_WIRE_SRC_UX 0x80000000u
+#define P2E_WIRE_SRC_GATE 0xC0000000u
 typedef struct p2e_wire_map_entry {
     uint32_t src, dst;
 } p2e_wire_map_entry;
@@ -222,7 +239,8 @@ int p2e_wire_map_create(p2e_ctx *ctx, int program, const p2e_wire_map_entry *ent
                         uint32_t degree, p2e_wire_map **out);
 void p2e_wire_map_destroy(p2e_ctx *ctx, p2e_wire_map *map);
 long p2e_assemble_wires(p2e_ctx *ctx, const p2e_wire_map *map, const uint64_t *cols, size_t ld, const uint64_t *aux,
-                        size_t ld_aux, const void *ux, int ux_u32, size_t ld_ux, uint64_t *wires, size_t wire_stride, size_t n);
+                        size_t ld_aux, const void *ux, int ux_u32, size_t ld_ux, const uint64_t *gate, size_t ld_gate,
+                        uint64_t *wires, size_t wire_stride, size_t n);
 
 /* ---- layout helper --------------------------------------------------------------------------------- */
 /* cols[ncols][ld] (column-major over the batch) -> rows[n][row_ld], one contiguous witness per signature:

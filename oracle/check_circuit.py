@@ -93,6 +93,7 @@ class Circuit:
         self.ux_in = ux
         self.aux = []                 # derived built-in-generator values (SURVEY 8(f) rank 1 order)
         self.ux = []                  # constraint-block values (8(f) rank 2), builder-call order
+        self.gate = []                # gate-internal values of the built-in gates (rest of 8(f) rank 1), call order
         self.record = record
         self.path = []
         self.gens = []                # (kind, field, first_col, ncols, label, operand sources)
@@ -292,8 +293,19 @@ class Circuit:
         return v
 
     def is_equal_zero(self, x):
+        """builder.is_equal(x, zero) [upstream-from-memory, plonky2 gadgets/arithmetic.rs]: EqualityGenerator sets
+        equal = (x == y) and inv = (x - y)^-1 (0 if equal); the gadget then builds not_equal = not(equal),
+        diff = x - y, not_equal_check = diff * inv, diff_normalized = diff * not_equal_check and connects
+        not_equal == not_equal_check, diff == diff_normalized.  The returned bool is an aux value; the five internal
+        targets go to the gate-internal vector."""
         v = int(x == 0)
         self._aux([v])
+        inv = pow(x, -1, P_GL) if x % P_GL else 0
+        diff = x % P_GL
+        check = diff * inv % P_GL
+        self.require(check == 1 - v, "is_equal", "not_equal != diff * inv")
+        self.require(diff * check % P_GL == diff, "is_equal", "diff != diff * not_equal_check")
+        self.gate.extend([1 - v, inv, diff, check, diff * check % P_GL])
         return v
 
     # ---- gadgets/nonnative.rs --------------------------------------------------------------------------------
@@ -525,6 +537,11 @@ class Circuit:
         xv = px.v + [0] * (NL - len(px))                        # .get(i).unwrap_or(&zero)
         yv = py.v + [0] * (NL - len(py))
         src = self._aux(xv + yv)
+        # [upstream-from-memory] one RandomAccessGate op per limb (9 x + 9 y): its generator also fills the bit wires of
+        # the access index, least significant first (log2(len(table)) of them)
+        nbits = (len(table) - 1).bit_length()
+        for _ in range(2 * NL):
+            self.gate.extend((idx >> b) & 1 for b in range(nbits))
         return T(xv, src[:NL]), T(yv, src[NL:])
 
     # ---- gadgets/curve_fixed_base.rs:18-66 ------------------------------------------------------------------------

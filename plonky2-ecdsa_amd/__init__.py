@@ -42,6 +42,8 @@ VERIFY_AUX_COLS = 8959      # built-in-generator columns (include/p2e.h p2e_aux_
 GLV_MUL_AUX_COLS = 4738
 VERIFY_UX_COLS = 249385     # constraint-block (U29 gate) columns (include/p2e.h p2e_ux_witness_batch)
 GLV_MUL_UX_COLS = 194361
+VERIFY_GATE_COLS = 10703    # gate-internal values of the built-in gates (include/p2e.h p2e_gate_internal_batch)
+GLV_MUL_GATE_COLS = 5621
 PROGRAM_VERIFY, PROGRAM_GLV_MUL = 0, 1
 
 # every symbol include/p2e.h declares
@@ -51,7 +53,7 @@ EXPORTS = (
     "p2e_add_many_witness_batch", "p2e_inv_witness_batch", "p2e_glv_decompose_batch", "p2e_limb_split",
     "p2e_limb_pack", "p2e_ecdsa_verify_witness_batch", "p2e_glv_mul_witness_batch", "p2e_columns_to_rows",
     "p2e_schedule_describe", "p2e_schedule_wiring", "p2e_wiring_const", "p2e_ux_witness_batch", "p2e_ux_describe", "p2e_ux_num_cols",
-    "p2e_wire_map_create", "p2e_wire_map_destroy", "p2e_assemble_wires",
+    "p2e_wire_map_create", "p2e_wire_map_destroy", "p2e_assemble_wires", "p2e_gate_internal_batch", "p2e_gate_internal_num_cols",
     "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
     "p2e_compact_layout", "p2e_columns_compact", "p2e_ecdsa_verify_witness_compact_batch",
     "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch", "p2e_compact_to_rows", "p2e_ecdsa_verify_batch", "p2e_biguint_div_rem_batch",
@@ -526,10 +528,23 @@ class Context:
             raise P2EError(f"p2e_wire_map_create failed ({rc}): {self._L.p2e_last_error().decode()}")
         return _WireMap(self, h, program, num_wires, degree, len(src))
 
-    def assemble_wires(self, wmap, cols=None, aux=None, ux=None, wires=None, n=None):
+    def gate_internal_batch(self, program, aux, n=None, ld_aux=None, gate=None, ld_gate=None):
+        """Gate-internal values of the built-in gates (equality gadget internals, RandomAccessGate index bits) from the
+        aux matrix: (10703 | 5621, n) uint64."""
+        n = n if n is not None else self._shape(aux)[1]
+        ld_aux = ld_aux if ld_aux is not None else _ld(aux)
+        if gate is None:
+            gate = self._cols(VERIFY_GATE_COLS if program == PROGRAM_VERIFY else GLV_MUL_GATE_COLS, n)
+        ld_gate = ld_gate if ld_gate is not None else _ld(gate)
+        self._L.p2e_gate_internal_batch.restype = C.c_long
+        self._check(self._L.p2e_gate_internal_batch(self._h, C.c_int(program), _ptr(aux), C.c_size_t(ld_aux), _ptr(gate),
+                                                    C.c_size_t(ld_gate), C.c_size_t(n)))
+        return gate
+
+    def assemble_wires(self, wmap, cols=None, aux=None, ux=None, gate=None, wires=None, n=None):
         """wires[i, wire * degree + row] = the mapped value of signature i: (n, num_wires * degree) int64, one plonky2 wire
         matrix per signature (zero where the map names nothing, when allocated here)."""
-        ref = cols if cols is not None else (aux if aux is not None else ux)
+        ref = next(m for m in (cols, aux, ux, gate) if m is not None)
         n = n if n is not None else self._shape(ref)[1]
         cells = wmap.num_wires * wmap.degree
         if wires is None:
@@ -544,7 +559,8 @@ class Context:
         self._L.p2e_assemble_wires.restype = C.c_long
         self._check(self._L.p2e_assemble_wires(self._h, wmap._h, _ptr(cols), C.c_size_t(_ld(cols) if cols is not None else 0),
                                                _ptr(aux), C.c_size_t(_ld(aux) if aux is not None else 0), _ptr(ux), C.c_int(u32),
-                                               C.c_size_t(_ld(ux) if ux is not None else 0), _ptr(wires),
+                                               C.c_size_t(_ld(ux) if ux is not None else 0), _ptr(gate),
+                                               C.c_size_t(_ld(gate) if gate is not None else 0), _ptr(wires),
                                                C.c_size_t(_ld(wires)), C.c_size_t(n)))
         return wires
 

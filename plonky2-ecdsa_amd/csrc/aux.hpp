@@ -162,6 +162,63 @@ P2E_HD void aux_put_split(E& e, const AuxArgs& A, const AuxItem& it, size_t i) {
     }
 }
 
+// ---- gate-internal values of the built-in gates on the path (the rest of SURVEY.md 8(f) rank 1) ------------------
+// [upstream-from-memory: plonky2 gadgets/arithmetic.rs is_equal + EqualityGenerator, gates/random_access.rs
+// RandomAccessGenerator]  Per window, in call order:
+//   is_equal(index, zero)   not_equal = 1 - equal, inv = index^-1 in Goldilocks (0 if index == 0), diff = index,
+//                           not_equal_check = diff * inv, diff_normalized = diff * not_equal_check          (5 values)
+//   random_access x 18      one RandomAccessGate op per selected limb (9 x, 9 y): the 4 bit wires of the access
+//                           index, least significant first                                                   (72 values)
+// fixed-base windows call is_equal first (gadgets/curve_fixed_base.rs:57-60), MSM digits random_access first
+// (gadgets/curve_msm.rs:68-70).  Everything is a function of the window's index, which is an aux column.
+constexpr u32 GATE_COLS_PER_WINDOW = 5 + 2 * NL * 4;
+struct GateItem {
+    u32 idx_col;    // aux column holding the window's index (4-bit digit / 4*m + n)
+    u32 gate_col;   // first column of this window's block
+    u32 ra_first;   // 1: random_access before is_equal (MSM digits)
+};
+struct GateArgs {
+    const u64* aux;
+    size_t ald;
+    u64* gate;
+    size_t gld, n;
+    const GateItem* items;
+    u64 inv16[16];  // Goldilocks inverses of 0..15 (inv16[0] = 0)
+};
+template <class E>
+P2E_HD void gate_put_eq(E& e, u32 idx, const u64* inv16) {
+    const u64 ne = idx != 0;
+    e.put(ne);          // not(equal)
+    e.put(inv16[idx]);  // EqualityGenerator inv
+    e.put(idx);         // diff = x - zero
+    e.put(ne);          // not_equal_check = diff * inv
+    e.put(idx);         // diff_normalized = diff * not_equal_check
+}
+template <class E>
+P2E_HD void gate_put_ra(E& e, u32 idx) {
+    P2E_UNROLL
+    for (int k = 0; k < 2 * NL; k++) {
+        P2E_UNROLL
+        for (int b = 0; b < 4; b++) e.put((idx >> b) & 1u);
+    }
+}
+template <class E>
+P2E_HD void body_gate(const GateArgs& A, int item, size_t i) {
+    const GateItem it = A.items[item];
+    const u32 idx = (u32)A.aux[(size_t)it.idx_col * A.ald + i] & 15u;
+    // the 16 inverses: a register select chain would be long; they sit in the kernel arguments (scalar loads)
+    E e = E::at(A.gate, A.gld, i, it.gate_col);
+    if (it.ra_first) {
+        gate_put_ra(e, idx);
+        gate_put_eq(e, idx, A.inv16);
+        e.flush();
+    } else {
+        gate_put_eq(e, idx, A.inv16);
+        gate_put_ra(e, idx);
+        e.flush();
+    }
+}
+
 template <class E>
 P2E_HD void body_aux(const AuxArgs& A, int item, size_t i) {
     const AuxItem it = A.items[item];

@@ -141,6 +141,13 @@ __global__ __launch_bounds__(BS) void k_aux(AuxArgs A, size_t first) {
     size_t i = lane_sig<(MODE & 1) != 0>(first);
     if ((MODE & 1) || i < A.n) body_aux<typename AuxEmitOf<MODE>::type>(A, (int)blockIdx.y, i);
 }
+// gate-internal values of the built-in gates, one (signature, window) per lane (aux.hpp body_gate); u64 only (the
+// equality gadget's inverse is a full Goldilocks element)
+template <int MODE>
+__global__ __launch_bounds__(BS) void k_gate(GateArgs A, size_t first) {
+    size_t i = lane_sig<(MODE & 1) != 0>(first);
+    if ((MODE & 1) || i < A.n) body_gate<typename AuxEmitOf<MODE>::type>(A, (int)blockIdx.y, i);
+}
 // constraint-block columns from the finished matrices: one (signature, generator) per lane (ux.hpp)
 template <int MODE>
 __global__ __launch_bounds__(BS) void k_ux(UxArgs A, size_t first) {
@@ -318,6 +325,8 @@ struct AssembleArgs {
     const void* ux;
     size_t uld;
     int ux_u32;
+    const u64* gate;
+    size_t gld;
     const u32* src;   // [count]
     const u32* dst;   // [count], ascending
     size_t count;
@@ -338,8 +347,10 @@ __global__ __launch_bounds__(BS) void k_assemble(AssembleArgs A) {
                 v = A.cols[(size_t)c * A.ld + sg];
             else if ((s >> 30) == 1)
                 v = A.aux[(size_t)c * A.ald + sg];
-            else
+            else if ((s >> 30) == 2)
                 v = A.ux_u32 ? (u64) static_cast<const u32*>(A.ux)[(size_t)c * A.uld + sg] : static_cast<const u64*>(A.ux)[(size_t)c * A.uld + sg];
+            else
+                v = A.gate[(size_t)c * A.gld + sg];
             tile[r][lane] = v;
         }
     }
@@ -454,6 +465,9 @@ struct DeviceProgram {
     std::vector<u32> ux_first, ux_count;
     u32 num_ux_cols = 0;
     UxItem* d_ux_items = nullptr;
+    std::vector<GateItem> gate_items;
+    u32 num_gate_cols = 0;
+    GateItem* d_gate_items = nullptr;
     // compact container (p2e_columns_compact): per-column slot, narrow / wide column counts
     std::vector<u32> compact_map;
     u32 num_narrow = 0, num_wide = 0;
@@ -543,6 +557,8 @@ static const DeviceProgram& host_program(int program) {
         P[0].ux_first = b0.ux_first;
         P[0].ux_count = b0.ux_count;
         P[0].num_ux_cols = b0.num_ux_cols;
+        P[0].gate_items = b0.gate_items;
+        P[0].num_gate_cols = b0.num_gate_cols;
         build_compact_map(P[0]);
         host::ScheduleBuilder b1;
         b1.glv_mul_circuit();
@@ -555,6 +571,8 @@ static const DeviceProgram& host_program(int program) {
         P[1].ux_first = b1.ux_first;
         P[1].ux_count = b1.ux_count;
         P[1].num_ux_cols = b1.num_ux_cols;
+        P[1].gate_items = b1.gate_items;
+        P[1].num_gate_cols = b1.num_gate_cols;
         build_compact_map(P[1]);
     });
     return P[program];
@@ -694,6 +712,10 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         c->progs[p].num_ux_cols = HP.num_ux_cols;
         HIP_TRY(hipMalloc(&c->progs[p].d_ux_items, sizeof(UxItem) * HP.ux_items.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_ux_items, HP.ux_items.data(), sizeof(UxItem) * HP.ux_items.size(), hipMemcpyHostToDevice));
+        c->progs[p].gate_items = HP.gate_items;
+        c->progs[p].num_gate_cols = HP.num_gate_cols;
+        HIP_TRY(hipMalloc(&c->progs[p].d_gate_items, sizeof(GateItem) * HP.gate_items.size()));
+        HIP_TRY(hipMemcpy(c->progs[p].d_gate_items, HP.gate_items.data(), sizeof(GateItem) * HP.gate_items.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc(&c->progs[p].d_aux_tab, sizeof(AuxTables)));
         HIP_TRY(hipMemcpy(c->progs[p].d_aux_tab, &HP.aux_tab, sizeof(AuxTables), hipMemcpyHostToDevice));
         c->progs[p].num_narrow = HP.num_narrow;
@@ -752,6 +774,7 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
     (void)hipFree(c->d_constv);
     for (auto& p : c->progs) {
         (void)hipFree(p.d_ux_items);
+        (void)hipFree(p.d_gate_items);
         (void)hipFree(p.d_ops);
         (void)hipFree(p.d_ops_plain);
         (void)hipFree(p.d_aux_items);
@@ -1594,21 +1617,21 @@ struct p2e_wire_map {
     u32* d_dst = nullptr;
     size_t count = 0;
     u32 num_wires = 0, degree = 0;
-    bool uses[3] = {false, false, false};
+    bool uses[4] = {false, false, false, false};
 };
 extern "C" int p2e_wire_map_create(p2e_ctx* c, int program, const p2e_wire_map_entry* entries, size_t count, uint32_t num_wires,
                                    uint32_t degree, p2e_wire_map** out) {
     if (!c || !out || program < 0 || program > 1 || (!entries && count) || !num_wires || !degree) return P2E_E_INVALID;
     const DeviceProgram& HP = host_program(program);
     const u64 cells = (u64)num_wires * degree;
-    const u32 limit[3] = {(u32)HP.prog.num_cols, HP.aux_tab.num_aux_cols, HP.num_ux_cols};
+    const u32 limit[4] = {(u32)HP.prog.num_cols, HP.aux_tab.num_aux_cols, HP.num_ux_cols, HP.num_gate_cols};
     std::vector<p2e_wire_map_entry> v(entries, entries + count);
     std::stable_sort(v.begin(), v.end(), [](const p2e_wire_map_entry& a, const p2e_wire_map_entry& b) { return a.dst < b.dst; });
     auto m = new p2e_wire_map();
     for (size_t k = 0; k < count; k++) {
         const u32 kind = v[k].src >> 30, col = v[k].src & 0x3FFFFFFFu;
-        if (kind > 2 || col >= limit[kind] || v[k].dst >= cells || (k && v[k].dst == v[k - 1].dst)) {
-            set_error(kind > 2 || col >= limit[kind < 3 ? kind : 0] ? "wire map: source column out of range"
+        if (col >= limit[kind] || v[k].dst >= cells || (k && v[k].dst == v[k - 1].dst)) {
+            set_error(col >= limit[kind] ? "wire map: source column out of range"
                       : v[k].dst >= cells                          ? "wire map: destination outside num_wires * degree"
                                                                    : "wire map: two entries share a destination");
             delete m;
@@ -1650,9 +1673,10 @@ extern "C" void p2e_wire_map_destroy(p2e_ctx* c, p2e_wire_map* m) {
     delete m;
 }
 extern "C" long p2e_assemble_wires(p2e_ctx* c, const p2e_wire_map* m, const uint64_t* cols, size_t ld, const uint64_t* aux,
-                                   size_t ld_aux, const void* ux, int ux_u32, size_t ld_ux, uint64_t* wires, size_t wire_stride, size_t n) {
+                                   size_t ld_aux, const void* ux, int ux_u32, size_t ld_ux, const uint64_t* gate, size_t ld_gate,
+                                   uint64_t* wires, size_t wire_stride, size_t n) {
     if (!c || !m || !wires || wire_stride < (size_t)m->num_wires * m->degree || (m->uses[0] && (!cols || ld < n)) ||
-        (m->uses[1] && (!aux || ld_aux < n)) || (m->uses[2] && (!ux || ld_ux < n))) {
+        (m->uses[1] && (!aux || ld_aux < n)) || (m->uses[2] && (!ux || ld_ux < n)) || (m->uses[3] && (!gate || ld_gate < n))) {
         set_error("p2e_assemble_wires: null matrix the map reads, ld < n, or wire_stride < num_wires * degree");
         return P2E_E_INVALID;
     }
@@ -1662,6 +1686,7 @@ extern "C" long p2e_assemble_wires(p2e_ctx* c, const p2e_wire_map* m, const uint
     if (cols) cols = S.in(cols, (size_t)DP.prog.num_cols * ld * 8);
     if (aux) aux = S.in(aux, (size_t)DP.aux_tab.num_aux_cols * ld_aux * 8);
     if (ux) ux = S.in((const char*)ux, (size_t)DP.num_ux_cols * ld_ux * (ux_u32 ? 4 : 8));
+    if (gate) gate = S.in(gate, (size_t)DP.num_gate_cols * ld_gate * 8);
     uint64_t* const host_wires = wires;
     void* d_stage = nullptr;
     if (S.host) {   // in-out buffer: positions no entry names keep the caller's values
@@ -1672,11 +1697,56 @@ extern "C" long p2e_assemble_wires(p2e_ctx* c, const p2e_wire_map* m, const uint
     }
     if (S.rc) return S.done(S.rc);
     ZERO_COUNTER(c);
-    AssembleArgs A{cols, ld, aux, ld_aux, ux, ld_ux, ux_u32, m->d_src, m->d_dst, m->count, wires, wire_stride, n};
+    AssembleArgs A{cols, ld, aux, ld_aux, ux, ld_ux, ux_u32, gate, ld_gate, m->d_src, m->d_dst, m->count, wires, wire_stride, n};
     dim3 grid((unsigned)((n + 63) / 64), (unsigned)((m->count + 63) / 64));
     hipLaunchKernelGGL(k_assemble, grid, dim3(BS), 0, c->stream, A);
     c->have_phases = false;
     return S.done(finish_call(c));
+}
+
+static u64 gl_pow_host(u64 a, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = gl_mul(r, a);
+        a = gl_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+extern "C" long p2e_gate_internal_batch(p2e_ctx* c, int program, const uint64_t* aux, size_t ld_aux, uint64_t* gate, size_t ld_gate,
+                                        size_t n) {
+    if (bad_common(c, n, ld_aux) || program < 0 || program > 1 || !aux || !gate || ld_gate < n) {
+        if (c && ld_gate < n) set_error("ld_gate < n");
+        return P2E_E_INVALID;
+    }
+    if (n == 0) return 0;
+    const DeviceProgram& DP = c->progs[program];
+    Staged S(c);
+    aux = S.in(aux, (size_t)DP.aux_tab.num_aux_cols * ld_aux * 8);
+    gate = S.out(gate, (size_t)DP.num_gate_cols * ld_gate * 8);
+    if (S.rc) return S.done(S.rc);
+    ZERO_COUNTER(c);
+    GateArgs A{};
+    A.aux = aux;
+    A.ald = ld_aux;
+    A.gate = gate;
+    A.gld = ld_gate;
+    A.n = n;
+    A.items = DP.d_gate_items;
+    A.inv16[0] = 0;
+    for (u64 d = 1; d < 16; d++) A.inv16[d] = gl_pow_host(d, P_GL - 2);
+    const unsigned items = (unsigned)DP.gate_items.size();
+    const bool wide_ok = (ld_gate % 2 == 0) && ((reinterpret_cast<uintptr_t>(gate) & 15) == 0) && !getenv("P2E_NARROW_STORES");
+    const size_t n_wide = wide_ok ? (n / BS) * BS : 0;
+    const dim3 gw((unsigned)(n_wide / BS), items), gt((unsigned)((n - n_wide + BS - 1) / BS), items);
+    if (n_wide) hipLaunchKernelGGL(k_gate<1>, gw, dim3(BS), 0, c->stream, A, (size_t)0);
+    if (n > n_wide) hipLaunchKernelGGL(k_gate<0>, gt, dim3(BS), 0, c->stream, A, n_wide);
+    c->have_phases = false;
+    return S.done(finish_call(c));
+}
+extern "C" long p2e_gate_internal_num_cols(int program) {
+    if (program < 0 || program > 1) return P2E_E_INVALID;
+    return (long)host_program(program).num_gate_cols;
 }
 
 extern "C" long p2e_ux_witness_batch(p2e_ctx* c, int program, const uint8_t* msg32, const uint8_t* r32, const uint8_t* s32,

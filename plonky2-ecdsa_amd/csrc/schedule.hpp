@@ -80,6 +80,8 @@ public:
     u32 num_ux_cols = 0;
     // built-in-generator columns: items for k_aux + their column map
     std::vector<AuxItem> aux_items;
+    std::vector<GateItem> gate_items;   // gate-internal values, one block per window (aux.hpp body_gate)
+    u32 num_gate_cols = 0;
     std::vector<AuxGen> aux_gens;
     AuxTables aux_tab{};
 
@@ -123,6 +125,7 @@ public:
     }
     // gadgets/split_nonnative.rs:25-50 / :52-72: split_le_base bits of every limb, then the digits built from them
     void split_nonnative_to_4_bit_limbs(NonNativeTarget v) {
+        split4_col_ = aux_col_;
         AuxItem it{};
         it.kind = AUX_SPLIT4;   // aux.hpp splits exactly the 9 limbs of a full scalar here ...
         assert(v.nl == NL);
@@ -186,6 +189,9 @@ public:
             AuxItem it = select_item(AUX_FBWIN, result);
             it.a = scalar.col;
             it.b = (u32)w;
+            // the window's digit = the third value of its (lower, upper, limb) triple behind the 261 split bits
+            gate_items.push_back({split4_col_ + (u32)NL * BITS + 3 * (u32)w + 2, num_gate_cols, 0});
+            num_gate_cols += GATE_COLS_PER_WINDOW;
             result = curve_conditional_add(result, r, base + 2 + 2 * NL);
             it.sumx = ops.back().col + COL_ADD_X3;
             it.sumy = ops.back().col + COL_ADD_Y3;
@@ -238,6 +244,8 @@ public:
             it.a = n.col;
             it.c = m.col;
             it.b = (u32)d;
+            gate_items.push_back({base, num_gate_cols, 1});   // the digit's index = mul_add(four, limb_m, limb_n): first aux value
+            num_gate_cols += GATE_COLS_PER_WINDOW;
             result = curve_conditional_add(result, r, base + 1 + 2 * NL + 2);
             it.sumx = ops.back().col + COL_ADD_X3;
             it.sumy = ops.back().col + COL_ADD_Y3;
@@ -348,7 +356,7 @@ public:
 
 private:
     static constexpr u32 SLOT_P_PLACEHOLDER = 0xFFFF00, SLOT_SP_PLACEHOLDER = 0xFFFF01;
-    u32 col_ = 0, aux_col_ = 0;
+    u32 col_ = 0, aux_col_ = 0, split4_col_ = 0;
     int num_cadd_ = 0;
     NonNativeTarget glv_k1_{FIELD_SCALAR}, glv_k2_{FIELD_SCALAR};
     BoolTarget glv_k1_neg_{0}, glv_k2_neg_{0};

@@ -13,10 +13,11 @@ import numpy as np
 
 from . import (PROGRAM_VERIFY, SRC_AUX, aux_num_cols, schedule_describe, schedule_wiring, ux_describe, ux_num_cols)
 
-WIRE_SRC_COLS, WIRE_SRC_AUX, WIRE_SRC_UX = 0x00000000, 0x40000000, 0x80000000
+WIRE_SRC_COLS, WIRE_SRC_AUX, WIRE_SRC_UX, WIRE_SRC_GATE = 0x00000000, 0x40000000, 0x80000000, 0xC0000000
 
 
-def synthetic_wire_map(program: int = PROGRAM_VERIFY, num_wires: int = 136, with_aux: bool = True, with_ux: bool = True):
+def synthetic_wire_map(program: int = PROGRAM_VERIFY, num_wires: int = 136, with_aux: bool = True, with_ux: bool = True,
+                       with_gate: bool = False):
     """(src uint32[], dst uint32[], num_wires, degree): dst = wire * degree + row."""
     gens = schedule_describe(program)
     wiring = schedule_wiring(program)
@@ -54,6 +55,9 @@ def synthetic_wire_map(program: int = PROGRAM_VERIFY, num_wires: int = 136, with
         packed.extend(WIRE_SRC_AUX | c for c in range(aux_num_cols(program)))
     if with_ux:
         packed.extend(WIRE_SRC_UX | c for c in range(ux_num_cols(program)))
+    if with_gate:
+        from . import VERIFY_GATE_COLS, GLV_MUL_GATE_COLS
+        packed.extend(WIRE_SRC_GATE | c for c in range(VERIFY_GATE_COLS if program == PROGRAM_VERIFY else GLV_MUL_GATE_COLS))
     first_packed_row = row
     rows = first_packed_row + -(-len(packed) // num_wires)
     degree = 1 << max(1, (rows - 1).bit_length())

@@ -59,6 +59,7 @@ pub const P2E_SRC_CONST: u32 = 0x8000_0000;
 pub const P2E_WIRE_SRC_COLS: u32 = 0x0000_0000;
 pub const P2E_WIRE_SRC_AUX: u32 = 0x4000_0000;
 pub const P2E_WIRE_SRC_UX: u32 = 0x8000_0000;
+pub const P2E_WIRE_SRC_GATE: u32 = 0xC000_0000;
 pub const P2E_COMPACT_WIDE: u32 = 0x8000_0000;
 
 #[link(name = "p2e_hip")]
@@ -117,7 +118,10 @@ extern "C" {
         degree: u32, out: *mut *mut P2eWireMap) -> i32;
     pub fn p2e_wire_map_destroy(ctx: *mut P2eCtx, map: *mut P2eWireMap);
     pub fn p2e_assemble_wires(ctx: *mut P2eCtx, map: *const P2eWireMap, cols: *const u64, ld: usize, aux: *const u64,
-        ld_aux: usize, ux: *const c_void, ux_u32: i32, ld_ux: usize, wires: *mut u64, wire_stride: usize, n: usize) -> i64;
+        ld_aux: usize, ux: *const c_void, ux_u32: i32, ld_ux: usize, gate: *const u64, ld_gate: usize, wires: *mut u64,
+        wire_stride: usize, n: usize) -> i64;
+    pub fn p2e_gate_internal_batch(ctx: *mut P2eCtx, program: i32, aux: *const u64, ld_aux: usize, gate: *mut u64,
+        ld_gate: usize, n: usize) -> i64;
 
     // ---- column maps (host only)
     pub fn p2e_schedule_describe(program: i32, out: *mut P2eGenDesc, cap: usize) -> i64;

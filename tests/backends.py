@@ -51,8 +51,17 @@ class EmuBackend:
         self.L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libp2e_emu.so"))
         for f in ("emu_verify", "emu_glv_mul", "emu_mul", "emu_checksum", "emu_add", "emu_sub", "emu_add_many",
                   "emu_inv", "emu_glv", "emu_split", "emu_pack", "emu_aux", "emu_aux_num_cols", "emu_verify_compact",
-                  "emu_glv_mul_compact", "emu_aux_compact", "emu_verify_only", "emu_div_rem", "emu_ux"):
+                  "emu_glv_mul_compact", "emu_aux_compact", "emu_verify_only", "emu_div_rem", "emu_ux", "emu_gate"):
             getattr(self.L, f).restype = C.c_long
+
+    def gate(self, program, aux):
+        """gate-internal values of the built-in gates from an aux matrix: (num_gate_cols, n) uint64"""
+        aux = np.ascontiguousarray(aux, np.uint64)
+        n = aux.shape[1]
+        k = 10703 if program == 0 else 5621
+        out = _z(k, n)
+        assert self.L.emu_gate(C.c_int(program), _p(aux), C.c_size_t(n), _p(out), C.c_size_t(n), C.c_size_t(n)) == k
+        return out
 
     def ux(self, program, inputs, cols, aux):
         """constraint-block columns from finished matrices: (num_ux_cols, n) uint64, err"""

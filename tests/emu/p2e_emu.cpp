@@ -334,6 +334,29 @@ long emu_ux(int program, const uint8_t* msg, const uint8_t* r, const uint8_t* s,
     }
     return (long)sb.num_ux_cols + 0 * bad;
 }
+// gate-internal values from an aux matrix (aux.hpp body_gate)
+long emu_gate(int program, const uint64_t* aux, size_t ald, uint64_t* gate, size_t gld, size_t n) {
+    host::ScheduleBuilder sb;
+    if (program == 0)
+        sb.verify_secp256k1_message_circuit();
+    else
+        sb.glv_mul_circuit();
+    GateArgs A{};
+    A.aux = aux; A.ald = ald; A.gate = gate; A.gld = gld; A.n = n; A.items = sb.gate_items.data();
+    A.inv16[0] = 0;
+    for (u64 d = 1; d < 16; d++) {
+        u64 r = 1, a = d, e = P_GL - 2;
+        while (e) {
+            if (e & 1) r = gl_mul(r, a);
+            a = gl_mul(a, a);
+            e >>= 1;
+        }
+        A.inv16[d] = r;
+    }
+    for (int item = 0; item < (int)sb.gate_items.size(); item++)
+        for (size_t i = 0; i < n; i++) body_gate<Emit>(A, item, i);
+    return (long)sb.num_gate_cols;
+}
 long emu_aux_num_cols(int program) {
     host::ScheduleBuilder sb;
     if (program == 0)

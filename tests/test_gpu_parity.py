@@ -634,6 +634,42 @@ def test_constraint_block_columns_match_the_replay_model(program):
     assert hb == 0 and np.array_equal(np.asarray(hu), h32[:, :3])
 
 
+@pytest.mark.parametrize("program", [0, 1])
+def test_gate_internal_values_on_the_gpu(program):
+    """p2e_gate_internal_batch (equality-gadget internals, RandomAccessGate index bits per window) from the GPU's own aux
+    matrix against the constraint replay's model; n = 300, padded stride, staged host-pointer path."""
+    import torch
+    import check_circuit as CC
+    import plonky2_ecdsa_amd as p2e
+    n = 300
+    sigs = p2e.synth_signatures(seed=4040, n=n)
+    ctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    if program == 0:
+        cols, _e, _v, bad = ctx.ecdsa_verify_witness_batch(*dev)
+        ks = None
+    else:
+        rng = R.SplitMix64(4041)
+        ks = [rng.below(R.N) for _ in range(n)]
+        cols, _e, _v, bad = ctx.glv_mul_witness_batch(dev[3], dev[4], torch.from_numpy(oracle_c.pack256(ks)).cuda())
+    aux, _ae, abad = ctx.aux_witness_batch(program, dev[4], cols)
+    k = p2e.VERIFY_GATE_COLS if program == 0 else p2e.GLV_MUL_GATE_COLS
+    big = torch.full((k, n + 10), -1, dtype=torch.int64, device="cuda")
+    gate = ctx.gate_internal_batch(program, aux, gate=big[:, :n])
+    torch.cuda.synchronize()
+    assert bad == 0 and abad == 0 and bool((big[:, n:] == -1).all())
+    host, hg = cols.cpu().numpy().view(np.uint64), gate.cpu().numpy().view(np.uint64)
+    for i in (0, 255, 256, 299):
+        if program == 0:
+            c = CC.check_verify(host[:, i], *CC.unpack_inputs(sigs, i))
+        else:
+            px, py = CC.unpack_inputs(sigs[3:5], i)
+            c = CC.check_glv_mul(host[:, i], px, py, ks[i])
+        assert np.array_equal(hg[:, i], np.array(c.gate, dtype=np.uint64))
+    hctx = p2e.Context(device=0, host_pointers=True)
+    assert np.array_equal(np.asarray(hctx.gate_internal_batch(program, aux.cpu().numpy().view(np.uint64)[:, :7].copy())), hg[:, :7])
+
+
 def test_assemble_wires_against_numpy():
     """SURVEY 8(f) rank 3 (p2e_assemble_wires): every column of the three matrices scattered into one plonky2 wire matrix
     per signature through a host-supplied (column -> wire * degree + row) map -- here the synthetic standard_ecc_config
@@ -651,19 +687,24 @@ def test_assemble_wires_against_numpy():
     ux, _ue, ubad = ctx.ux_witness_batch(0, dev, cols, aux)                   # u32
     assert bad == abad == ubad == 0 and int(valid.sum()) == n
     hc, ha, hu = cols.cpu().numpy().view(np.uint64), aux.cpu().numpy().view(np.uint64), ux.cpu().numpy().view(np.uint32)
+    hg = None
 
     def reference(src, dst, cells):
         out = np.zeros((n, cells), dtype=np.uint64)
         kind, col = src >> 30, src & 0x3FFFFFFF
-        for k, m in ((0, hc), (1, ha), (2, hu)):
+        for k, m in ((0, hc), (1, ha), (2, hu), (3, hg)):
             sel = kind == k
-            out[:, dst[sel]] = m[col[sel]].T
+            if sel.any():
+                out[:, dst[sel]] = m[col[sel]].T
         return out
 
-    src, dst, nw, deg = synthetic_wire_map(0)
-    assert nw == 136 and len(src) == 378878
+    gate = ctx.gate_internal_batch(0, aux)
+    torch.cuda.synchronize()
+    hg = gate.cpu().numpy().view(np.uint64)
+    src, dst, nw, deg = synthetic_wire_map(0, with_gate=True)
+    assert nw == 136 and len(src) == 378878 + p2e.VERIFY_GATE_COLS
     wm = ctx.wire_map(0, src, dst, nw, deg)
-    wires = ctx.assemble_wires(wm, cols, aux, ux)
+    wires = ctx.assemble_wires(wm, cols, aux, ux, gate)
     torch.cuda.synchronize()
     assert np.array_equal(wires.cpu().numpy().view(np.uint64), reference(src, dst, nw * deg))
     # untouched cells keep the caller's values; a random map (sources repeated, destinations scattered); u64 ux matrix

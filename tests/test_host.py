@@ -389,3 +389,37 @@ def test_constraint_block_columns_match_the_replay_model_and_the_golden_digests(
     bad[12345] ^= np.uint64(1)
     with pytest.raises(CC.ConstraintViolation):
         (CC.check_verify if program == 0 else CC.check_glv_mul)(cols[:, 0], *CC.unpack_inputs([inputs[:, k, :] for k in range(inputs.shape[1])], 0), ux=bad)
+
+
+@pytest.mark.parametrize("program", [0, 1])
+def test_gate_internal_values_match_the_replay_model(program):
+    """The rest of SURVEY 8(f) rank 1 (csrc/aux.hpp body_gate, compiled for the CPU): per window the equality gadget's
+    internals and the RandomAccessGate index bits, derived from the aux matrix, against the values the constraint replay
+    records where the gadgets call is_equal / random_access ([upstream-from-memory] semantics, "parity unpinned")."""
+    import check_circuit as CC
+    if program == 0:
+        cols, inputs, valid = pc.load_verify_golden()
+        aux = np.load(os.path.join(pc.GOLD, "aux_golden.npz"))["verify"]
+    else:
+        g = np.load(os.path.join(pc.GOLD, "glv_mul_golden.npz"))
+        cols, inputs, valid = g["cols"], g["inputs"], np.ones(g["cols"].shape[1], np.uint8)
+        aux = np.load(os.path.join(pc.GOLD, "aux_golden.npz"))["glv_mul"]
+    gate = EmuBackend().gate(program, aux)
+    assert gate.shape[0] == (p2e.VERIFY_GATE_COLS if program == 0 else p2e.GLV_MUL_GATE_COLS)
+    for i in range(cols.shape[1]):
+        if not valid[i]:
+            continue
+        ins = CC.unpack_inputs([inputs[:, k, :] for k in range(inputs.shape[1])], i)
+        c = (CC.check_verify if program == 0 else CC.check_glv_mul)(cols[:, i], *ins)
+        assert np.array_equal(gate[:, i], np.array(c.gate, dtype=np.uint64))
+    # the equality internals satisfy the gadget's own relations in Goldilocks: diff * inv == not_equal, diff * not_equal == diff
+    # (fixed-base windows call is_equal before the 18 random accesses, MSM digits after: gadgets/curve_fixed_base.rs:57-60,
+    # gadgets/curve_msm.rs:68-70)
+    blocks = gate[:, 0].reshape(-1, 77)
+    n_fb = 66 if program == 0 else 0
+    for w, blk in enumerate(blocks):
+        off = 0 if w < n_fb else 72
+        ne, inv, diff, chk, dn = [int(v) for v in blk[off:off + 5]]
+        assert ne in (0, 1) and chk == ne and dn == diff and diff < 16 and (diff * inv - ne) % R.P_GL == 0
+        bits = blk[5:] if w < n_fb else blk[:72]
+        assert all(sum(int(b) << k for k, b in enumerate(bits[4 * j:4 * j + 4])) == diff for j in range(18))
