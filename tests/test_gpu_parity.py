@@ -437,6 +437,21 @@ def test_full_size_batch_properties():
     sel_rows = [r for kind, f, _n, _l in items if kind in ("fixed_base_window", "msm_digit")
                 for r in range(f + (2 if kind == "fixed_base_window" else 1), f + (2 if kind == "fixed_base_window" else 1) + 18)]
     assert int((aux_full[torch.tensor(sel_rows[::5], device="cuda")] >> 29).ne(0).sum()) == 0
+    # constraint-block (U29 gate) columns and gate-internal values of the same batch: 65 GB of u32, every value a U29
+    # value; three sampled signatures go through the constraint replay with all four matrices attached
+    import check_circuit as CC
+    del aux_full, idx
+    torch.cuda.empty_cache()
+    ux, uerr, ubad = ctx.ux_witness_batch(p2e.PROGRAM_VERIFY, dev, cols, aux)
+    gate = ctx.gate_internal_batch(p2e.PROGRAM_VERIFY, aux)
+    torch.cuda.synchronize()
+    assert ubad == 0 and int(uerr.sum()) == 0
+    assert all(int((ux[c0:c0 + 8192] >> 29).ne(0).sum()) == 0 for c0 in range(0, ux.shape[0], 8192))   # in slices: 65 GB
+    for i in (0, 30000, n - 1):
+        ti = torch.tensor([i], device="cuda")
+        c = CC.check_verify(cols[:, ti].cpu().numpy().view(np.uint64)[:, 0], *CC.unpack_inputs(sigs, i),
+                            aux=aux[:, ti].cpu().numpy().view(np.uint64)[:, 0], ux=ux[:, ti].cpu().numpy().view(np.uint32)[:, 0])
+        assert np.array_equal(gate[:, ti].cpu().numpy().view(np.uint64)[:, 0], np.array(c.gate, dtype=np.uint64))
 
 
 def test_gpu_output_passes_the_constraint_replay():
