@@ -160,58 +160,6 @@ struct ChainStateQ {
     U256 acc;
 };
 
-// Second operands that do not depend on the ops in front of them (fixed-base table entries, the finished MSM window
-// table, constant points) are fetched ONE OP AHEAD, their window digits two ops ahead: a lone wave per SIMD has
-// nothing to hide a dependent digit -> table index -> point load chain behind (about half of the chain kernel's
-// cycles were s_waitcnt), and on gfx9 loads and stores return in order, so a load issued after an op's scratch stores
-// also waits for those.  Fetched at the top of the previous op, the loads sit in front of that op's stores.
-struct P2Ahead {   // stage 1, two ops ahead: the window digit and (MSM table) the entry's resolved source id
-    u32 digit;
-    uint16_t src2;
-};
-struct P2Fetch {   // stage 2, one op ahead: the operand itself, affine
-    Aff pt;
-    uint16_t src2;
-    u32 digit;
-    int t;   // the op this operand belongs to, -1: none
-};
-P2E_HD bool p2_fetchable(const OpDesc& op, bool table_affine) {
-    if (op.kind == OP_DBL) return false;
-    const u32 k = ref_kind(op.ref2);
-    return k == R_FBTAB || k == R_CONST || (k == R_MSMTAB && table_affine);
-}
-P2E_HD P2Ahead p2_ahead(const Buffers& B, size_t i, const OpDesc& op) {
-    P2Ahead a;
-    a.digit = 1;
-    a.src2 = 0;
-    if (op.kind == OP_DBL) return a;
-    const u32 k = ref_kind(op.ref2);
-    if (k == R_FBTAB) {
-        a.digit = B.dig4[(size_t)ref_id(op.ref2) * B.n + i];
-    } else if (k == R_MSMTAB) {
-        a.digit = B.dig2[(size_t)ref_id(op.ref2) * B.n + i];
-        a.src2 = B.msrc[(size_t)ref_id(op.ref2) * B.n + i];
-    }
-    return a;
-}
-P2E_HD P2Fetch p2_fetch(const Buffers& B, size_t i, const OpDesc& op, const P2Ahead& a, int t) {
-    P2Fetch f;
-    f.t = t;
-    f.digit = a.digit;
-    const u32 k = ref_kind(op.ref2);
-    if (k == R_FBTAB) {
-        f.src2 = (uint16_t)(SRC_FB_BIT | (ref_id(op.ref2) * 16 + a.digit));
-        f.pt = B.fbtab[ref_id(op.ref2) * 16 + a.digit];
-    } else if (k == R_CONST) {
-        f.src2 = (uint16_t)(ref_id(op.ref2) | DYN_CONST_BIT);
-        f.pt = B.cpts[ref_id(op.ref2)];
-    } else {   // R_MSMTAB, the table already in affine form
-        f.src2 = a.src2;
-        f.pt = load_aff_src(B, i, a.src2);
-    }
-    return f;
-}
-
 // Loaded values that are only consumed after the branches rejoin make the compiler put its s_waitcnt at the JOIN,
 // i.e. on every path -- and since vmcnt is in-order that wait also drains the operand fetches issued for the next
 // op.  Touching the values inside the (rare) branch that loaded them keeps the wait in there.
@@ -284,10 +232,10 @@ P2E_HD P1Sel quad_first_operand(const Program& G, const Buffers& B, size_t i, co
 }
 
 // body_chain_op (pipeline.hpp) for a quad: same operand resolution, same scratch outputs; the four lanes share the
-// stores (role 0: X + the operand ids, 1: Y, 2: Z + prefix, 3: W).  No loads in here on the hot path: the first
-// operand was settled by quad_first_operand, the second fetched one op ahead (pf).
+// stores (quad_store_op).  This generic form serves the ops outside the two hot loops (window-table build, unblinding
+// adds, the final add); its operand loads are settled where they are issued.
 P2E_HD void body_chain_op_quad(const Program& G, const Buffers& B, size_t i, int role, int t, const OpDesc& op, bool table_affine,
-                               const P1Sel& s1, const P2Fetch& pf, ChainStateQ& st) {
+                               const P1Sel& s1, ChainStateQ& st) {
     const uint16_t src1 = s1.src1;
     const Jac& p1 = s1.p1;
     if (role == 0) B.src[(size_t)(2 * t) * B.n + i] = src1;
@@ -299,12 +247,7 @@ P2E_HD void body_chain_op_quad(const Program& G, const Buffers& B, size_t i, int
         u32 digit = 1;
         uint16_t src2;
         bool z2one = (op.flags & F_Z2ONE) != 0;
-        if (pf.t == t) {   // fetched one op ahead, affine
-            p2 = jac_from_aff(pf.pt);
-            src2 = pf.src2;
-            digit = pf.digit;
-            z2one = true;
-        } else {           // operands that depend on the ops right in front (window-table build): rare, loaded here
+        {
             if (ref_kind(op.ref2) == R_FBTAB) {
                 Aff a = load_fbtab(B, i, ref_id(op.ref2), digit);
                 p2 = jac_from_aff(a);
@@ -497,8 +440,6 @@ P2E_HD void body_chain_range_quad(const Program& G, const Buffers& B, size_t i, 
     st.out.X = st.out.Y = st.out.Z = st.p1.X = st.p1.Y = st.p1.Z = st.out_zz = st.p1_zz = u256_zero();
     st.acc = continue_prefix ? range_product(B, i, lo - 1) : u256_small(1);
     const int lb = G.msm_loop_begin, le = lb + 3 * G.msm_loop_iters;
-    P2Fetch none;
-    none.t = -1;
     int t = lo;
     while (t < hi) {
         const OpDesc op = load_op(B.ops, t);
@@ -536,7 +477,7 @@ P2E_HD void body_chain_range_quad(const Program& G, const Buffers& B, size_t i, 
             t += done;
         } else {
             const P1Sel s1 = quad_first_operand(G, B, i, op, st);
-            body_chain_op_quad(G, B, i, role, t, op, table_affine, s1, none, st);
+            body_chain_op_quad(G, B, i, role, t, op, table_affine, s1, st);
             t++;
         }
     }
