@@ -86,7 +86,8 @@ def input_t(name, value):
 
 
 class Circuit:
-    def __init__(self, cols, aux=None, ux=None, record=True):
+    def __init__(self, cols, aux=None, ux=None, record=True, curve=None):
+        self.curve = curve or R.SECP256K1
         self.cols = cols
         self.cur = 0                  # registration-order cursor into cols
         self.aux_in = aux
@@ -310,7 +311,7 @@ class Circuit:
 
     # ---- gadgets/nonnative.rs --------------------------------------------------------------------------------
     def modulus(self, field):
-        return const_t(MODULI[field])
+        return const_t(self.curve.moduli[field])
 
     def range_check_result(self, x, field, what):               # :180-190: cmp_biguint(x, modulus) connected to one
         self.require(self.cmp_biguint(x, self.modulus(field), what) == 1, what, "range check: value > modulus")
@@ -367,7 +368,7 @@ class Circuit:
 
     def mul_nonnative(self, x, y, field, range_check=False):    # :390-464
         what = "mul_nonnative"
-        m = MODULI[field]
+        m = self.curve.moduli[field]
         # gate wire order gates/mul_nonnative.rs:41-59,384-390: r[9], q[9], check_sum[17], then b[16] of the CheckSumGate row
         c0, o = self.read("mul", field, 2 * NL + (2 * NL - 1) + (2 * NL - 2), (x, y))
         r, q, cs, b = o[0:9], o[9:18], o[18:35], o[35:51]
@@ -439,7 +440,7 @@ class Circuit:
     def curve_assert_valid(self, p):                            # :123-135
         x, y = p
         F = FIELD_BASE
-        a, b = const_t(R.CURVE_A), const_t(R.CURVE_B)
+        a, b = const_t(self.curve.a), const_t(self.curve.b)
         y2 = self.mul_nonnative(y, y, F, True)
         x2 = self.mul_nonnative(x, x, F, False)
         x3 = self.mul_nonnative(x2, x, F, False)
@@ -457,7 +458,7 @@ class Circuit:
         dy = self.add_nonnative(y, y, F, False)
         idy = self.inv_nonnative(dy, F, False)
         xx = self.mul_nonnative(x, x, F, False)
-        t = self.add_many_nonnative([xx, xx, xx, const_t(R.CURVE_A)], F, False)
+        t = self.add_many_nonnative([xx, xx, xx, const_t(self.curve.a)], F, False)
         lam = self.mul_nonnative(t, idy, F, False)
         lam2 = self.mul_nonnative(lam, lam, F, False)
         xd = self.add_nonnative(x, x, F, False)
@@ -548,22 +549,23 @@ class Circuit:
     def fixed_base_curve_mul(self, base, scalar):
         nwin = len(scalar) * 8
         limbs = self.split_4(scalar)
-        rando = R.rando_point()
+        C = self.curve
+        rando = C.hash_point(32)
         result = const_point(rando)
         point = base
         for i, limb in enumerate(limbs):
             if i >= nwin:
                 break
             with self.scope(f"win{i}"):
-                muls = R.fixed_base_window(point)
+                muls = C.fixed_base_window(point)
                 tbl = [const_point(muls[0])] + [const_point(q) for q in muls]
                 should_add = self.not_(self.is_equal_zero(limb))
                 r = self.random_access_curve_points(limb, tbl)
                 result = self.curve_conditional_add(result, r, should_add, False)
             for _ in range(4):
-                point = R.ec_double(point)
+                point = C.double(point)
         with self.scope("unblind"):
-            return self.curve_add(result, const_point(R.ec_neg(rando)), True)
+            return self.curve_add(result, const_point(C.neg(rando)), True)
 
     # ---- gadgets/curve_msm.rs:21-79 ---------------------------------------------------------------------------------
     def curve_msm(self, p, q, n, m):
@@ -642,6 +644,80 @@ class Circuit:
             point = self.curve_add(point1, point2, True)
         self.connect_nonnative(r, point[0], "verify: connect_nonnative(r, point.x)")
 
+    # ---- gadgets/curve.rs:137-147, :245-285, gadgets/curve_windowed_mul.rs:52-72,131-173,
+    # gadgets/ecdsa.rs:55-78.  The rand() points of precompute_window (:57) and curve_scalar_mul (:253) are inputs.
+    def curve_neg(self, p, range_check=False):
+        return p[0], self.neg_nonnative(p[1], FIELD_BASE, range_check)
+
+    def precompute_window(self, p, g):
+        neg = const_point(self.curve.neg(g))
+        multiples = [const_point(g)]
+        for i in range(1, 16):
+            multiples.append(self.curve_add(p, multiples[i - 1], True))
+        for i in range(1, 16):
+            multiples[i] = self.curve_add(neg, multiples[i], True)
+        return multiples
+
+    def curve_scalar_mul_windowed(self, p, n, g, range_check=True):
+        C = self.curve
+        windows = self.split_4(n)
+        starting_point = C.hash_point(25)
+        spm = starting_point
+        for _ in range(len(windows) * 4):
+            spm = C.double(spm)
+        result = const_point(starting_point)
+        with self.scope("precompute"):
+            pre = self.precompute_window(p, g)
+        for i in reversed(range(len(windows))):
+            with self.scope(f"window{i}"):
+                result = self.curve_repeated_double(result, 4, False)
+                to_add = self.random_access_curve_points(windows[i], pre)
+                should_add = self.not_(self.is_equal_zero(windows[i]))
+                result = self.curve_conditional_add(result, to_add, should_add, False)
+        with self.scope("unblind"):
+            to_add = self.curve_neg(const_point(spm), False)
+            return self.curve_add(result, to_add, range_check)
+
+    def curve_scalar_mul(self, p, n, rando, range_check=True):
+        bits = self._bits(n)                                    # split_nonnative_to_bits gadgets/nonnative.rs:566-582
+        randot = const_point(rando)
+        # add_virtual_affine_point_target + connect_affine_point: 9-limb virtual targets that carry the constant's limbs
+        # (connect_biguint asserts the limbs beyond the shorter operand to be zero, gadgets/biguint.rs:181-196)
+        vx, vy = randot[0].v + [0] * (NL - len(randot[0])), randot[1].v + [0] * (NL - len(randot[1]))
+        result = (T(vx, [("virt", "result.x", k) for k in range(NL)]), T(vy, [("virt", "result.y", k) for k in range(NL)]))
+        self.connect_nonnative(randot[0], result[0], "curve_scalar_mul: result == rando")
+        self.connect_nonnative(randot[1], result[1], "curve_scalar_mul: result == rando")
+        two_i_times_p = p
+        for i, bit in enumerate(bits):
+            with self.scope(f"bit{i}"):
+                not_bit = self.not_(bit)
+                rp = self.curve_add(result, two_i_times_p, False)
+                xt = self.mul_biguint_by_bool(rp[0], bit)
+                xf = self.mul_biguint_by_bool(result[0], not_bit)
+                yt = self.mul_biguint_by_bool(rp[1], bit)
+                yf = self.mul_biguint_by_bool(result[1], not_bit)
+                new_x = self.add_nonnative(xt, xf, FIELD_BASE, False)
+                new_y = self.add_nonnative(yt, yf, FIELD_BASE, False)
+                result = (new_x, new_y)
+                two_i_times_p = self.curve_double(two_i_times_p, False)
+        with self.scope("unblind"):
+            neg_r = self.curve_neg(randot, False)
+            return self.curve_add(result, neg_r, range_check)
+
+    def verify_p256_message(self, msg, r, s, pk, g):
+        with self.scope("assert_valid"):
+            self.curve_assert_valid(pk)
+        c = self.inv_nonnative(s, FIELD_SCALAR, False)
+        u1 = self.mul_nonnative(msg, c, FIELD_SCALAR, True)
+        u2 = self.mul_nonnative(r, c, FIELD_SCALAR, True)
+        with self.scope("fixed_base"):
+            point1 = self.fixed_base_curve_mul(self.curve.g, u1)
+        with self.scope("windowed_mul"):
+            point2 = self.curve_scalar_mul_windowed(pk, u2, g, True)
+        with self.scope("final_add"):
+            point = self.curve_add(point1, point2, True)
+        self.connect_nonnative(r, point[0], "verify: connect_nonnative(r, point.x)")
+
     def finish(self):
         self.require(self.cur == len(self.cols), "end", f"{len(self.cols) - self.cur} witness columns were never read")
         if self.aux_in is not None:
@@ -670,6 +746,29 @@ def check_verify(cols, msg, r, s, pkx, pky, aux=None, ux=None):
 def check_glv_mul(cols, px, py, k, aux=None, ux=None):
     c = Circuit(cols, aux=aux, ux=ux)
     c.glv_mul((input_t("pkx", px), input_t("pky", py)), input_t("k", k))
+    c.finish()
+    return c
+
+
+def check_windowed_mul(curve, cols, px, py, k, g, aux=None):
+    """curve_scalar_mul_windowed(p, k) (gadgets/curve_windowed_mul.rs:131-173) with precompute_window's point g"""
+    c = Circuit(cols, aux=aux, curve=curve)
+    pt = c.curve_scalar_mul_windowed((input_t("px", px), input_t("py", py)), input_t("k", k), g, True)
+    c.finish()
+    return c, (pt[0].value(), pt[1].value())
+
+
+def check_scalar_mul(curve, cols, px, py, k, rando, aux=None):
+    """curve_scalar_mul(p, k) (gadgets/curve.rs:245-285) with blinding point rando"""
+    c = Circuit(cols, aux=aux, curve=curve)
+    pt = c.curve_scalar_mul((input_t("px", px), input_t("py", py)), input_t("k", k), rando, True)
+    c.finish()
+    return c, (pt[0].value(), pt[1].value())
+
+
+def check_verify_p256(cols, msg, r, s, pkx, pky, g, aux=None):
+    c = Circuit(cols, aux=aux, curve=R.P256)
+    c.verify_p256_message(input_t("msg", msg), input_t("r", r), input_t("s", s), (input_t("pkx", pkx), input_t("pky", pky)), g)
     c.finish()
     return c
 

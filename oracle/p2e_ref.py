@@ -164,6 +164,85 @@ def ec_mul(k, p):
 G = (GX, GY)
 
 
+class Curve:
+    """A short-Weierstrass curve of the crate (curve/curve_types.rs:15-42): base modulus p, group order n, a, b, G.
+    The native helpers below are only used for CONSTANTS (blinding points, fixed-base tables) and to synthesise
+    inputs; FIELD_BASE / FIELD_SCALAR index `moduli`."""
+
+    def __init__(self, name, p, n, a, b, g):
+        self.name, self.p, self.n, self.a, self.b, self.g = name, p, n, a % p, b % p, g
+        self.moduli = {FIELD_BASE: p, FIELD_SCALAR: n}
+        self._fb = {}
+
+    def add(self, p1, p2):                                      # curve/curve_adds.rs (affine, incl. the neutral element)
+        if p1 is None:
+            return p2
+        if p2 is None:
+            return p1
+        (x1, y1), (x2, y2) = p1, p2
+        if x1 == x2:
+            if (y1 + y2) % self.p == 0:
+                return None
+            return self.double(p1)
+        lam = (y2 - y1) * pow(x2 - x1, -1, self.p) % self.p
+        x3 = (lam * lam - x1 - x2) % self.p
+        return x3, (lam * (x1 - x3) - y1) % self.p
+
+    def double(self, pt):                                       # curve/curve_types.rs:83-102
+        if pt is None:
+            return None
+        x1, y1 = pt
+        lam = (3 * x1 * x1 + self.a) * pow(2 * y1, -1, self.p) % self.p
+        x3 = (lam * lam - 2 * x1) % self.p
+        return x3, (lam * (x1 - x3) - y1) % self.p
+
+    def neg(self, pt):
+        return None if pt is None else (pt[0], (-pt[1]) % self.p)
+
+    def mul(self, k, pt):
+        r = None
+        while k:
+            if k & 1:
+                r = self.add(r, pt)
+            pt = self.double(pt)
+            k >>= 1
+        return r
+
+    def on_curve(self, pt):
+        x, y = pt
+        return (y * y - (x * x * x + self.a * x + self.b)) % self.p == 0
+
+    def hash_point(self, nbytes):
+        """KeccakHash::<N>::hash_no_pad(&[F::ZERO]) read as a little-endian integer, times G
+        (gadgets/curve_fixed_base.rs:34-38 and gadgets/curve_msm.rs:33-37 with N = 32,
+        gadgets/curve_windowed_mul.rs:140-144 with N = 25).  [upstream-from-memory: plonky2 hash/keccak.rs --
+        KeccakHash<N> keeps the first N bytes of keccak256 of the field elements' 8-byte LE encodings;
+        from_noncanonical_biguint does not reduce]"""
+        scalar = int.from_bytes(keccak256(bytes(8))[:nbytes], "little")
+        return self.mul(scalar, self.g)
+
+    def fixed_base_window(self, point):
+        """t * point for t = 1..15 (gadgets/curve_fixed_base.rs:45-54)."""
+        if point not in self._fb:
+            out, acc = [], None
+            for _ in range(15):
+                acc = self.add(point, acc)
+                out.append(acc)
+            self._fb[point] = out
+        return self._fb[point]
+
+
+SECP256K1 = Curve("secp256k1", P, N, CURVE_A, CURVE_B, G)
+# curve/p256.rs:15-57, field/p256_base.rs:14-17, field/p256_scalar.rs:5
+P256_P = 0xffffffff00000001000000000000000000000000ffffffffffffffffffffffff
+P256_N = 0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551
+P256 = Curve("p256", P256_P, P256_N, P256_P - 3,
+             0x5AC635D8AA3A93E7B3EBBD55769886BC651D06B0CC53B0F63BCE3C3E27D2604B,
+             (0x6B17D1F2E12C4247F8BCE6E563A440F277037D812DEB33A0F4A13945D898C296,
+              0x4FE342E2FE1A7F9B8EE7EB4A7C0F9E162BCE33576B315ECECBB6406837BF51F5))
+CURVES = {"secp256k1": SECP256K1, "p256": P256}
+
+
 def rando_point():
     """gadgets/curve_fixed_base.rs:34-38 == gadgets/curve_msm.rs:33-37.
 
@@ -433,7 +512,8 @@ class Walker:
     ``ops`` the (kind, field, first_col, ncols, label) table that include/p2e.h's
     p2e_schedule_describe mirrors."""
 
-    def __init__(self):
+    def __init__(self, curve=None):
+        self.curve = curve or SECP256K1
         self.cols = []
         self.ops = []
         self._path = []
@@ -477,24 +557,24 @@ class Walker:
 
     # -- gadgets/nonnative.rs
     def add_nonnative(self, a, b, field):                       # :245-276
-        s, ov = gen_add(a, b, MODULI[field])
+        s, ov = gen_add(a, b, self.curve.moduli[field])
         self._rec("add", field, s + [ov])
         return s
 
     def sub_nonnative(self, a, b, field):                       # :356-388
-        d, ov = gen_sub(a, b, MODULI[field])
+        d, ov = gen_sub(a, b, self.curve.moduli[field])
         self._rec("sub", field, d + [ov])
         return d
 
     def add_many_nonnative(self, xs, field):                    # :310-353
         if len(xs) == 1:
             return xs[0]
-        s, ov = gen_add_many(xs, MODULI[field])
+        s, ov = gen_add_many(xs, self.curve.moduli[field])
         self._rec("add_many", field, s + [ov])
         return s
 
     def mul_nonnative(self, x, y, field):                       # :390-464
-        m = MODULI[field]
+        m = self.curve.moduli[field]
         xw = list(x) + [0] * (NL - len(x))
         yw = list(y) + [0] * (NL - len(y))
         r, q, cs = gen_mul(xw, yw, m)
@@ -504,7 +584,7 @@ class Walker:
         return r
 
     def inv_nonnative(self, x, field):                          # :502-536
-        inv, div = gen_inv(x, MODULI[field])
+        inv, div = gen_inv(x, self.curve.moduli[field])
         self._rec("inv", field, inv + div)
         return inv
 
@@ -526,8 +606,8 @@ class Walker:
     # -- gadgets/curve.rs
     def curve_assert_valid(self, p):                            # :123-135
         x, y = p
-        a = const_limbs(CURVE_A)
-        b = const_limbs(CURVE_B)
+        a = const_limbs(self.curve.a)
+        b = const_limbs(self.curve.b)
         y2 = self.mul_nonnative(y, y, FIELD_BASE)
         x2 = self.mul_nonnative(x, x, FIELD_BASE)
         x3 = self.mul_nonnative(x2, x, FIELD_BASE)
@@ -545,7 +625,7 @@ class Walker:
         dy = self.add_nonnative(y, y, F)
         idy = self.inv_nonnative(dy, F)
         xx = self.mul_nonnative(x, x, F)
-        t = self.add_many_nonnative([xx, xx, xx, const_limbs(CURVE_A)], F)
+        t = self.add_many_nonnative([xx, xx, xx, const_limbs(self.curve.a)], F)
         lam = self.mul_nonnative(t, idy, F)
         lam2 = self.mul_nonnative(lam, lam, F)
         xd = self.add_nonnative(x, x, F)
@@ -630,22 +710,23 @@ class Walker:
     def fixed_base_curve_mul(self, base, scalar):
         nwin = len(scalar) * 8
         limbs = self.split_4(scalar)
-        rando = rando_point()
+        C = self.curve
+        rando = C.hash_point(32)
         result = const_point(rando)
         point = base
         for i, limb in enumerate(limbs):
             if i >= nwin:
                 break
             with self.scope(f"win{i}"):
-                muls = fixed_base_window(point)                 # t*P_i, t=1..15 ; slot 0 := slot 1 (Q8')
+                muls = C.fixed_base_window(point)               # t*P_i, t=1..15 ; slot 0 := slot 1 (Q8')
                 tbl = [const_point(muls[0])] + [const_point(q) for q in muls]
                 should_add = self.not_(self.is_equal_zero(limb))
                 r = self.random_access_point(limb, tbl)
                 result = self.curve_conditional_add(result, r, should_add)
             for _ in range(4):
-                point = ec_double(point)
+                point = C.double(point)
         with self.scope("unblind"):
-            return self.curve_add(result, const_point(ec_neg(rando)))
+            return self.curve_add(result, const_point(C.neg(rando)))
 
     # -- gadgets/curve_msm.rs:21-79
     def curve_msm(self, p, q, n, m):
@@ -684,6 +765,83 @@ class Walker:
             spm = ec_double(spm)
         with self.scope("unblind"):
             return self.curve_add(result, const_point(ec_neg(spm)))
+
+    # -- gadgets/curve.rs:137-147
+    def curve_neg(self, p):
+        return p[0], self.neg_nonnative(p[1], FIELD_BASE)
+
+    # -- gadgets/curve_windowed_mul.rs:52-72.  `g` = the point precompute_window draws with rand() at circuit-build
+    # time (:57): an input of the restatement
+    def precompute_window(self, p, g):
+        C = self.curve
+        neg = const_point(C.neg(g))
+        multiples = [const_point(g)]
+        for i in range(1, 16):
+            multiples.append(self.curve_add(p, multiples[i - 1]))
+        for i in range(1, 16):
+            multiples[i] = self.curve_add(neg, multiples[i])
+        return multiples
+
+    # -- gadgets/curve_windowed_mul.rs:131-173
+    def curve_scalar_mul_windowed(self, p, n, g):
+        C = self.curve
+        windows = self.split_4(n)
+        starting_point = C.hash_point(25)
+        spm = starting_point
+        for _ in range(len(windows) * 4):
+            spm = C.double(spm)
+        result = const_point(starting_point)
+        with self.scope("precompute"):
+            pre = self.precompute_window(p, g)
+        for i in reversed(range(len(windows))):
+            with self.scope(f"window{i}"):
+                result = self.curve_repeated_double(result, 4)
+                to_add = self.random_access_point(windows[i], pre)
+                should_add = self.not_(self.is_equal_zero(windows[i]))
+                result = self.curve_conditional_add(result, to_add, should_add)
+        with self.scope("unblind"):
+            to_add = self.curve_neg(const_point(spm))
+            return self.curve_add(result, to_add)
+
+    # -- gadgets/curve.rs:245-285.  `rando` = the rand() blinding point of :253, an input as above
+    def curve_scalar_mul(self, p, n, rando):
+        bits = self._bits(n)                                    # split_nonnative_to_bits gadgets/nonnative.rs:566-582
+        self._aux("bits", bits)
+        randot = const_point(rando)
+        result = (pad9(randot[0]), pad9(randot[1]))             # add_virtual_affine_point_target + connect_affine_point
+        two_i_times_p = p
+        for i, bit in enumerate(bits):
+            with self.scope(f"bit{i}"):
+                not_bit = self.not_(bit)
+                rp = self.curve_add(result, two_i_times_p)
+                xt = self.mul_by_bool(rp[0], bit)
+                xf = self.mul_by_bool(result[0], not_bit)
+                yt = self.mul_by_bool(rp[1], bit)
+                yf = self.mul_by_bool(result[1], not_bit)
+                new_x = self.add_nonnative(xt, xf, FIELD_BASE)
+                new_y = self.add_nonnative(yt, yf, FIELD_BASE)
+                result = (new_x, new_y)
+                two_i_times_p = self.curve_double(two_i_times_p)
+        with self.scope("unblind"):
+            neg_r = self.curve_neg(randot)
+            return self.curve_add(result, neg_r)
+
+    # -- gadgets/ecdsa.rs:55-78
+    def verify_p256_message(self, msg, r, s, pk, g):
+        C = self.curve
+        with self.scope("assert_valid"):
+            ok_curve = self.curve_assert_valid(pk)
+        c = self.inv_nonnative(s, FIELD_SCALAR)
+        u1 = self.mul_nonnative(msg, c, FIELD_SCALAR)
+        u2 = self.mul_nonnative(r, c, FIELD_SCALAR)
+        with self.scope("fixed_base"):
+            point1 = self.fixed_base_curve_mul(C.g, u1)
+        with self.scope("windowed_mul"):
+            point2 = self.curve_scalar_mul_windowed(pk, u2, g)
+        with self.scope("final_add"):
+            point = self.curve_add(point1, point2)
+        ok_sig = pad9(point[0]) == pad9(r)
+        return ok_curve and ok_sig
 
     # -- gadgets/glv.rs:53-104
     def decompose_secp256k1_scalar(self, k):
@@ -785,6 +943,40 @@ def glv_mul_witness_aux(pkx, pky, k):
     (_pt, ok) = w.glv_mul((limbs_of(pkx, NL), limbs_of(pky, NL)), limbs_of(k, NL))
     assert len(w.aux) == NUM_GLV_MUL_AUX, len(w.aux)
     return w.cols, w.aux, ok, w.aux_ops
+
+
+def windowed_mul_witness(curve, px, py, k, g):
+    """curve_scalar_mul_windowed(p, k) with precompute_window's random point `g`: (cols, aux, ops, result point)"""
+    w = Walker(curve)
+    pt = w.curve_scalar_mul_windowed((limbs_of(px, NL), limbs_of(py, NL)), limbs_of(k, NL), g)
+    return w.cols, w.aux, w.ops, (value_of(pt[0]), value_of(pt[1]))
+
+
+def scalar_mul_witness(curve, px, py, k, rando):
+    """curve_scalar_mul(p, k) with blinding point `rando`"""
+    w = Walker(curve)
+    pt = w.curve_scalar_mul((limbs_of(px, NL), limbs_of(py, NL)), limbs_of(k, NL), rando)
+    return w.cols, w.aux, w.ops, (value_of(pt[0]), value_of(pt[1]))
+
+
+def verify_p256_witness(msg, r, s, pkx, pky, g):
+    """verify_p256_message_circuit: (cols, aux, ok, ops)"""
+    w = Walker(P256)
+    ok = w.verify_p256_message(limbs_of(msg, NL), limbs_of(r, NL), limbs_of(s, NL), (limbs_of(pkx, NL), limbs_of(pky, NL)), g)
+    return w.cols, w.aux, ok, w.ops
+
+
+def synth_signature_curve(curve, rng):
+    """sign_message curve/ecdsa.rs:25-40 on any curve of the crate"""
+    while True:
+        sk, msg, k = rng.below(curve.n), rng.below(curve.n), rng.below(curve.n)
+        pk = curve.mul(sk, curve.g)
+        rr = curve.mul(k, curve.g)
+        r = canon(rr[0], curve.n)
+        s = pow(k, -1, curve.n) * (msg + r * sk) % curve.n
+        if r == 0 or s == 0:
+            continue
+        return msg, r, s, pk[0], pk[1]
 
 
 # deterministic synthetic inputs (splitmix64), restating curve/ecdsa.rs:25-40 sign_message
