@@ -312,6 +312,49 @@ long p2e_schedule_wiring(int program, p2e_gen_wiring *out, size_t cap);
 /* value of constant `id` as 32 little-endian bytes; returns its limb count (0 for the zero constant), < 0: unknown id */
 int p2e_wiring_const(uint32_t id, uint8_t out32[32]);
 
+/* ---- curve programs --------------------------------------------------------- */
+/* The crate's other scalar-multiplication gadgets, on either of its curves, through the same phases as the built-in
+ * programs:
+ *   P2E_CP_WINDOWED_MUL  curve_scalar_mul_windowed(p, n, true)  gadgets/curve_windowed_mul.rs:131-173   98 185 columns
+ *   P2E_CP_SCALAR_MUL    curve_scalar_mul(p, n, true)           gadgets/curve.rs:245-285               139 354 columns
+ *   P2E_CP_VERIFY        verify_p256_message_circuit            gadgets/ecdsa.rs:55-78 (P-256 only)    115 557 columns
+ * Both gadgets blind with a point drawn by rand() WHILE THE CIRCUIT IS BUILT (precompute_window
+ * gadgets/curve_windowed_mul.rs:57, curve_scalar_mul gadgets/curve.rs:253), so their witness depends on the build:
+ * a program object stands for one built circuit and takes that point (canonical affine coordinates, 32 little-endian
+ * bytes each) as an argument -- the Rust side passes the point its builder drew.  Column order = generator
+ * registration order as for the built-in programs (p2e_curve_program_describe / _wiring mirror
+ * p2e_schedule_describe / _wiring; constant ids of a program resolve through p2e_curve_program_const: 2c / 2c + 1 =
+ * x / y of constant point c, 0x8000 + j = scalar constant j).  The built-in-generator targets of these gadgets are
+ * numbered and described (p2e_curve_program_aux_describe; the wiring refers to them) but have no fill pass yet.
+ * A program belongs to the context's device; u64 column matrix only. */
+#define P2E_CURVE_SECP256K1 0
+#define P2E_CURVE_P256 1
+#define P2E_CP_WINDOWED_MUL 1
+#define P2E_CP_SCALAR_MUL 2
+#define P2E_CP_VERIFY 3
+typedef struct p2e_curve_program p2e_curve_program;
+int p2e_curve_program_create(p2e_ctx *ctx, int kind, int curve, const uint8_t *blind_x32, const uint8_t *blind_y32,
+                             p2e_curve_program **out);
+void p2e_curve_program_destroy(p2e_ctx *ctx, p2e_curve_program *prog);
+long p2e_curve_program_num_cols(const p2e_curve_program *prog);
+long p2e_curve_program_num_aux_cols(const p2e_curve_program *prog);
+size_t p2e_curve_program_scratch_bytes(const p2e_curve_program *prog, size_t n);
+long p2e_curve_program_describe(const p2e_curve_program *prog, p2e_gen_desc *out, size_t cap);
+long p2e_curve_program_wiring(const p2e_curve_program *prog, p2e_gen_wiring *out, size_t cap);
+long p2e_curve_program_aux_describe(const p2e_curve_program *prog, p2e_aux_desc *out, size_t cap);
+int p2e_curve_program_const(const p2e_curve_program *prog, uint32_t id, uint8_t out32[32]);
+/* replaces the run_once bodies of every generator curve_scalar_mul_windowed / curve_scalar_mul registers for a batch
+ * of (point, scalar) pairs; cols[num_cols][ld].  valid: always 1 unless flagged (the gadgets connect nothing). */
+long p2e_curve_mul_witness_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *px32, const uint8_t *py32,
+                                 const uint8_t *k32, uint64_t *cols, size_t n, size_t ld, uint8_t *err, uint8_t *valid);
+/* the same for verify_p256_message_circuit; valid = curve_assert_valid's connect and r == x both hold */
+long p2e_p256_verify_witness_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *msg32, const uint8_t *r32,
+                                   const uint8_t *s32, const uint8_t *pkx32, const uint8_t *pky32, uint64_t *cols, size_t n,
+                                   size_t ld, uint8_t *err, uint8_t *valid);
+/* synthetic valid signatures on a curve (host only; P2E_CURVE_*), same stream layout as p2e_synth_signatures */
+int p2e_synth_signatures_curve(int curve, uint64_t seed, size_t first, size_t n, uint8_t *msg32, uint8_t *r32, uint8_t *s32,
+                               uint8_t *pkx32, uint8_t *pky32);
+
 /* ---- synthetic inputs (host only): valid signatures per curve/ecdsa.rs:25-40 sign_message with
  * sk, msg, nonce drawn from splitmix64(seed, i).  Host buffers of n*32 bytes each. -------------------- */
 int p2e_synth_signatures(uint64_t seed, size_t first, size_t n, uint8_t *msg32, uint8_t *r32, uint8_t *s32,

@@ -44,6 +44,11 @@ constexpr uint8_t ERR_LIMB_RANGE = 1, ERR_VALUE_GE_2_256 = 2, ERR_INVERSE_OF_ZER
 struct ModP {  // Secp256K1Base
     static constexpr int NC = 2;
     static constexpr bool kFourFolds = false;
+    static constexpr bool kBarrett = false;
+    P2E_HD static u32 k527(int i) {   // 2^-527 mod m (fe_inv_bingcd)
+        constexpr u32 v[8] = {0xe02a12f7u, 0x77735922u, 0x2a6654feu, 0x518f6c84u, 0xc27a180au, 0x8c412c0du, 0x7a893ee2u, 0x81526b84u};
+        return v[i];
+    }
     P2E_HD static u32 c(int i) {
         constexpr u32 v[2] = {0x000003D1u, 0x00000001u};
         return v[i];
@@ -63,6 +68,11 @@ struct ModP {  // Secp256K1Base
 struct ModN {  // Secp256K1Scalar
     static constexpr int NC = 5;
     static constexpr bool kFourFolds = true;
+    static constexpr bool kBarrett = false;
+    P2E_HD static u32 k527(int i) {
+        constexpr u32 v[8] = {0x26886774u, 0x4608c517u, 0xb48257cbu, 0xed12990bu, 0xde6b7db0u, 0x51477db0u, 0x95d85510u, 0xd3235b67u};
+        return v[i];
+    }
     P2E_HD static u32 c(int i) {
         constexpr u32 v[5] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 0x00000001u};
         return v[i];
@@ -75,6 +85,47 @@ struct ModN {  // Secp256K1Scalar
     P2E_HD static u32 m29(int i) {
         constexpr u32 v[9] = {0x10364141u, 0x1E92F466u, 0x12280EEFu, 0x1DB9CD5Eu, 0x1FFFEBAAu,
                               0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x00FFFFFFu};
+        return v[i];
+    }
+};
+
+// NIST P-256 (reference field/p256_base.rs:14-17, field/p256_scalar.rs:5).  Neither modulus is
+// 2^256 - small (C would be 224 bits), so these two reduce by Barrett (reduce_barrett below): mu = floor(2^512 / m).
+struct ModP256 {  // P256Base
+    static constexpr bool kBarrett = true;
+    P2E_HD static u32 m(int i) {
+        constexpr u32 v[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000001u, 0xFFFFFFFFu};
+        return v[i];
+    }
+    P2E_HD static u32 m29(int i) {
+        constexpr u32 v[9] = {0x1FFFFFFFu, 0x1FFFFFFFu, 0x1FFFFFFFu, 0x000001FFu, 0x00000000u, 0x00000000u, 0x00040000u, 0x1FE00000u, 0x00FFFFFFu};
+        return v[i];
+    }
+    P2E_HD static u32 mu(int i) {
+        constexpr u32 v[9] = {0x00000003u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFEu, 0xFFFFFFFEu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0x00000000u, 0x00000001u};
+        return v[i];
+    }
+    P2E_HD static u32 k527(int i) {
+        constexpr u32 v[8] = {0x0019FFFFu, 0x000E0000u, 0xFFDE0000u, 0x00200000u, 0xFFF60000u, 0xFFEDFFFFu, 0x001E0000u, 0xFFEDFFFFu};
+        return v[i];
+    }
+};
+struct ModN256 {  // P256Scalar
+    static constexpr bool kBarrett = true;
+    P2E_HD static u32 m(int i) {
+        constexpr u32 v[8] = {0xFC632551u, 0xF3B9CAC2u, 0xA7179E84u, 0xBCE6FAADu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0xFFFFFFFFu};
+        return v[i];
+    }
+    P2E_HD static u32 m29(int i) {
+        constexpr u32 v[9] = {0x1C632551u, 0x1DCE5617u, 0x05E7A13Cu, 0x0DF55B4Eu, 0x1FFFFBCEu, 0x1FFFFFFFu, 0x0003FFFFu, 0x1FE00000u, 0x00FFFFFFu};
+        return v[i];
+    }
+    P2E_HD static u32 mu(int i) {
+        constexpr u32 v[9] = {0xEEDF9BFEu, 0x012FFD85u, 0xDF1A6C21u, 0x43190552u, 0xFFFFFFFFu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0x00000000u, 0x00000001u};
+        return v[i];
+    }
+    P2E_HD static u32 k527(int i) {
+        constexpr u32 v[8] = {0x1C04824Bu, 0xD4C529B9u, 0x5C057EEDu, 0x2F26EFCEu, 0xEEB19D0Au, 0x88F0E491u, 0x33DB97B2u, 0x02F57AA6u};
         return v[i];
     }
 };
@@ -431,6 +482,90 @@ P2E_HD void reduce_wide(const u32* prod /*8+NH*/, u32* r /*8*/, u32* q /*9 or nu
     for (int i = 0; i < 8; i++) r[i] = lo[i];
 }
 
+// low NR words of a[NA] * b[NB] (product scanning, only the columns below NR)
+template <int NA, int NB, int NR>
+P2E_HD void mul_lo(const u32* a, const u32* b, u32* r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 acc = 0;
+    u32 acc2 = 0;
+    P2E_UNROLL
+    for (int k = 0; k < NR; k++) {
+        P2E_UNROLL
+        for (int i = 0; i < NA; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < NB) {
+                asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc"
+                    : "+v"(acc), "+v"(acc2)
+                    : "v"(a[i]), "v"(b[j])
+                    : "vcc");
+            }
+        }
+        r[k] = (u32)acc;
+        acc = (acc >> 32) | ((u64)acc2 << 32);
+        acc2 = 0;
+    }
+#else
+    P2E_UNROLL
+    for (int i = 0; i < NR; i++) r[i] = 0;
+    P2E_UNROLL
+    for (int i = 0; i < NA; i++) {
+        u64 c = 0;
+        P2E_UNROLL
+        for (int j = 0; j < NB; j++) {
+            if (i + j < NR) {
+                u64 t = (u64)a[i] * b[j] + r[i + j] + c;
+                r[i + j] = (u32)t;
+                c = t >> 32;
+            }
+        }
+        if (i + NB < NR) r[i + NB] = (u32)c;
+    }
+#endif
+}
+
+// Barrett reduction (HAC 14.42 with b = 2^32, k = 8) of prod = hi:lo with NH high words, for any modulus with its top
+// word set: q1 = prod >> 224, q3 = (q1 * mu) >> 288 with mu = floor(2^512 / m), then q3 <= floor(prod / m) <= q3 + 2 and
+// r = (prod - q3 * m) mod 2^288 needs at most two subtractions of m.  Also yields the exact integer quotient the
+// MulNonnative / Inverse witness generators need.  (64 + (NH+1)*9 + ~44 multiplications for NH = 8, against 73 for
+// the fold chain of secp256k1's p: the price of a modulus without the 2^256 - small shape.)
+template <class MOD, int NH, bool WANT_Q>
+P2E_HD void reduce_barrett(const u32* prod /*8+NH*/, u32* r /*8*/, u32* q /*9 or null*/) {
+    constexpr int NQ = NH + 1;
+    u32 muw[9], mw[8];
+    P2E_UNROLL
+    for (int i = 0; i < 9; i++) muw[i] = MOD::mu(i);
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) mw[i] = MOD::m(i);
+    u32 q2[NQ + 9];
+    mul_wide<NQ, 9>(prod + 7, muw, q2);
+    const u32* q3 = q2 + 9;   // NQ words
+    u32 r2[9];
+    mul_lo<NQ, 8, 9>(q3, mw, r2);
+    u32 t[9];
+    u32 br = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 9; i++) t[i] = subb32(i < 8 + NH ? prod[i] : 0u, r2[i], br);
+    u32 extra = 0;
+    P2E_UNROLL
+    for (int pass = 0; pass < 2; pass++) {
+        const bool ge = t[8] != 0 || geq_mod<MOD>(t);
+        u32 b2 = 0;
+        P2E_UNROLL
+        for (int i = 0; i < 9; i++) {
+            const u32 d = subb32(t[i], i < 8 ? mw[i] : 0u, b2);
+            t[i] = ge ? d : t[i];
+        }
+        extra += ge ? 1u : 0u;
+    }
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) r[i] = t[i];
+    if (WANT_Q) {
+        u32 c = 0;
+        P2E_UNROLL
+        for (int i = 0; i < 9; i++) q[i] = addc32(i < NQ ? q3[i] : 0u, i == 0 ? extra : 0u, c);
+    }
+}
+
 // 16-word product -> (r, q): specialised path for p, generic fold chain for n
 template <class MOD, bool WANT_Q>
 P2E_HD void reduce16(const u32* prod, u32* r, u32* q);
@@ -442,6 +577,14 @@ template <>
 P2E_HD void reduce16<ModN, false>(const u32* prod, u32* r, u32* q) { reduce_wide<ModN, 8, false>(prod, r, q); }
 template <>
 P2E_HD void reduce16<ModN, true>(const u32* prod, u32* r, u32* q) { reduce_wide<ModN, 8, true>(prod, r, q); }
+template <>
+P2E_HD void reduce16<ModP256, false>(const u32* prod, u32* r, u32* q) { reduce_barrett<ModP256, 8, false>(prod, r, q); }
+template <>
+P2E_HD void reduce16<ModP256, true>(const u32* prod, u32* r, u32* q) { reduce_barrett<ModP256, 8, true>(prod, r, q); }
+template <>
+P2E_HD void reduce16<ModN256, false>(const u32* prod, u32* r, u32* q) { reduce_barrett<ModN256, 8, false>(prod, r, q); }
+template <>
+P2E_HD void reduce16<ModN256, true>(const u32* prod, u32* r, u32* q) { reduce_barrett<ModN256, 8, true>(prod, r, q); }
 
 // ------------------------------------------------------------------------------------------------
 // field ops on canonical values
@@ -554,7 +697,10 @@ P2E_HD U256 fe_mul_small(const U256& x, u32 f) {   // x * f mod m, x < 2^256
     }
     t[8] = (u32)c;
     U256 r;
-    reduce_wide<MOD, 1, false>(t, r.w, nullptr);
+    if constexpr (MOD::kBarrett)
+        reduce_barrett<MOD, 1, false>(t, r.w, nullptr);
+    else
+        reduce_wide<MOD, 1, false>(t, r.w, nullptr);
     return r;
 }
 // |fa * a  +-  fb * b| >> 31 for magnitudes fa, fb <= 2^31 and signs na, nb (true = negative); the sum is an
@@ -674,13 +820,9 @@ P2E_HD bool fe_inv_bingcd(const U256& y, U256& result) {
         v = fe_add<MOD>(uf1, vg1);
     }
     // 2^-527 mod m
-    U256 k;
-    {
-        const u32 kp[8] = {0xe02a12f7u, 0x77735922u, 0x2a6654feu, 0x518f6c84u, 0xc27a180au, 0x8c412c0du, 0x7a893ee2u, 0x81526b84u};
-        const u32 kn[8] = {0x26886774u, 0x4608c517u, 0xb48257cbu, 0xed12990bu, 0xde6b7db0u, 0x51477db0u, 0x95d85510u, 0xd3235b67u};
-        P2E_UNROLL
-        for (int i = 0; i < 8; i++) k.w[i] = MOD::NC == 2 ? kp[i] : kn[i];
-    }
+    U256 k;   // 2^-527 mod m
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) k.w[i] = MOD::k527(i);
     result = fe_mul<MOD>(v, k);
     bool ok = b[0] == 1;
     P2E_UNROLL
@@ -690,8 +832,25 @@ P2E_HD bool fe_inv_bingcd(const U256& y, U256& result) {
     return ok;
 }
 
+// a^(m-2) mod m by plain square-and-multiply (the low word of every modulus here is >= 2: no borrow).  Only the
+// fallback of fe_inv for the moduli without a dedicated ladder, i.e. reached by zero inputs.
 template <class MOD>
-P2E_HD U256 fe_inv(const U256& a);
+P2E_HD U256 fe_inv_fermat(const U256& a) {
+    U256 acc = a;  // the top bit of m - 2 is set
+    for (int i = 254; i >= 0; i--) {
+        acc = fe_sqr<MOD>(acc);
+        u32 word = MOD::m(i >> 5);
+        if ((i >> 5) == 0) word -= 2;
+        if ((word >> (i & 31)) & 1) acc = fe_mul<MOD>(acc, a);
+    }
+    return acc;
+}
+template <class MOD>
+P2E_HD U256 fe_inv(const U256& a) {
+    U256 r;
+    if (fe_inv_bingcd<MOD>(a, r)) return r;
+    return fe_inv_fermat<MOD>(a);
+}
 template <>
 P2E_HD U256 fe_inv<ModP>(const U256& a) {
     U256 r;

@@ -17,6 +17,7 @@
 #include "prims.hpp"
 #include "quad.hpp"
 #include "schedule.hpp"
+#include "curve_program.hpp"
 
 using namespace p2e;
 
@@ -606,8 +607,9 @@ static ScratchLayout scratch_layout(const Program& G, size_t n) {
     L.ax = take((size_t)G.num_slots * n * 32);
     L.ay = take((size_t)G.num_slots * n * 32);
     L.dig4 = take((size_t)FB_WINDOWS * n);
-    L.dig2 = take((size_t)MSM_DIGITS * n);
-    L.msrc = take((size_t)MSM_DIGITS * n * 2);
+    const size_t rows = (size_t)(G.cp_rows > MSM_DIGITS ? G.cp_rows : MSM_DIGITS);   // curve programs: up to 261 bit rows
+    L.dig2 = take(rows * n);
+    L.msrc = take(rows * n * 2);
     L.dyn = take((size_t)G.num_cadd * n * 2);
     L.src = take((size_t)G.num_ops * 2 * n * 2);
     L.err32 = take(n * 4);
@@ -1903,3 +1905,5 @@ extern "C" int p2e_synth_signatures(uint64_t seed, size_t first, size_t n, uint8
     }
     return 0;
 }
+
+#include "curve_api.inc"

@@ -18,7 +18,9 @@ namespace p2e {
 
 // ---- schedule description shared by host and device ---------------------------------------------------
 enum OpKind : uint8_t { OP_ADD = 0, OP_DBL = 1, OP_CADD = 2 };
-enum RefKind : uint32_t { R_SLOT = 0, R_CONST = 1, R_DYN = 2, R_FBTAB = 3, R_MSMTAB = 4 };
+// R_SELSLOT (curve programs, curves.hpp): operand 2 of a conditional add = the result of op (id & 0xFFF), selected by
+// the bit in digit row (id >> 12) -- curve_scalar_mul's  result + 2^i p  (gadgets/curve.rs:257-270)
+enum RefKind : uint32_t { R_SLOT = 0, R_CONST = 1, R_DYN = 2, R_FBTAB = 3, R_MSMTAB = 4, R_SELSLOT = 5 };
 // F_NO_AFFINE: the op's result is only ever consumed inside an expansion run (run-walked in registers by
 // k_expand_runs), so phase B skips its Jacobian -> affine conversion
 enum OpFlags : uint8_t { F_Z1ONE = 1, F_Z2ONE = 2, F_CHECK_R = 4, F_NO_AFFINE = 8 };
@@ -94,6 +96,9 @@ struct Program {
     int32_t chain_begin[4], chain_end[4];
     // the MSM loop: msm_loop_iters iterations of (double, double, conditional add) starting at op msm_loop_begin
     int32_t msm_loop_begin, msm_loop_iters;
+    // curve programs (curves.hpp; zero for the two built-in programs): kind, digit rows of the per-signature table /
+    // bit selects, the column and constant of the one curve_neg(constant) generator, ops of the per-signature table
+    int32_t cp_kind, cp_rows, cp_neg_col, cp_neg_const, cp_table_ops;
 };
 
 struct Buffers {
@@ -304,8 +309,10 @@ P2E_HD Jac jac_select3(bool c1, const Jac& a, bool c2, const Jac& b, const Jac& 
 // table_affine: the MSM window table has already been through phase B (its 23-op piece is inverted before
 // the loop pieces start), so table operands are read in affine form and the 73 window additions are
 // mixed additions (11 multiplications instead of 17).
+template <class CV = Secp256k1, bool GENERIC = false>
 P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, bool table_affine, ChainState& st,
                           const Aff* lds_fb = nullptr, u32 lds_w0 = 0) {
+    typedef typename CV::Fp F;
     const OpDesc op = load_op(B.ops, t);
     size_t o = (size_t)t * B.n + i;
     JacW res;
@@ -316,13 +323,17 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, b
     p1 = jac_select3(from_out, st.out, from_p1, st.p1, p1);
     B.src[(size_t)(2 * t) * B.n + i] = src1;
     if (op.kind == OP_DBL) {
-        res = jac_dbl(p1);
+        res = jac_dbl_cv<CV>(p1);
     } else {
         Jac p2;
         u32 digit = 1;
         uint16_t src2;
         bool z2one = (op.flags & F_Z2ONE) != 0;
-        if (ref_kind(op.ref2) == R_FBTAB) {
+        if (GENERIC && ref_kind(op.ref2) == R_SELSLOT) {
+            digit = B.dig2[(size_t)(ref_id(op.ref2) >> 12) * B.n + i];
+            src2 = (uint16_t)(ref_id(op.ref2) & 0xFFFu);
+            p2 = load_jac_src(B, i, src2, z2one);
+        } else if (ref_kind(op.ref2) == R_FBTAB) {
             Aff a = load_fbtab(B, i, ref_id(op.ref2), digit, lds_fb, lds_w0);
             p2 = jac_from_aff(a);
             src2 = (uint16_t)(SRC_FB_BIT | (ref_id(op.ref2) * 16 + digit));
@@ -340,13 +351,13 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, b
         B.src[(size_t)(2 * t + 1) * B.n + i] = (uint16_t)(src2 | (digit != 0 ? SRC_SEL_BIT : 0));
         // the Z-one specialisations only skip multiplications by one: pick by the host-known flags
         if ((op.flags & F_Z1ONE) && z2one)
-            res = jac_add<true, true>(p1, p2);
+            res = jac_add_cv<CV, true, true>(p1, p2);
         else if (z2one)
-            res = jac_add<false, true>(p1, p2);
+            res = jac_add_cv<CV, false, true>(p1, p2);
         else if (op.flags & F_Z1ONE)
-            res = jac_add<true, false>(p1, p2);
+            res = jac_add_cv<CV, true, false>(p1, p2);
         else
-            res = jac_add<false, false>(p1, p2);
+            res = jac_add_cv<CV, false, false>(p1, p2);
         if (op.kind == OP_CADD) B.dyn[(size_t)op.cadd_idx * B.n + i] = digit != 0 ? (uint16_t)t : src1;
     }
     // X, Y of a result are read back only by phase B's affine conversion and by the first op of a later chain
@@ -364,7 +375,7 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, b
         err_or(&B.err[i], ERR_INVERSE_OF_ZERO);
         z = u256_small(1);
     }
-    st.acc = fp_mul(st.acc, z);
+    st.acc = fe_mul<F>(st.acc, z);
     st.p1 = p1;
     st.p1_id = (op.flags & F_Z1ONE) ? (uint16_t)0xFFFF : src1;   // an affine operand has no Z to carry
     st.out = res.p;
@@ -372,21 +383,23 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, b
 }
 // Product of the Z3 values (zeros replaced by one) of ops [lo, hi) given the prefix array: prefix of the
 // last op times its own Z3.
+template <class CV = Secp256k1>
 P2E_HD U256 range_product(const Buffers& B, size_t i, int last) {
     size_t o = (size_t)last * B.n + i;
     U256 z = B.PZ[o];
     if (u256_is_zero(z)) z = u256_small(1);
-    return fp_mul(B.PREF[o], z);
+    return fe_mul<typename CV::Fp>(B.PREF[o], z);
 }
 // ops [lo, hi) of one chain, in order (the range may be a piece of a chain: everything a later piece needs
 // lives in scratch).  continue_prefix: the range extends the inversion batch of the ops just before it.
+template <class CV = Secp256k1, bool GENERIC = false>
 P2E_HD void body_chain_range(const Program& G, const Buffers& B, size_t i, int lo, int hi, bool table_affine,
                              bool continue_prefix, const Aff* lds_fb = nullptr, u32 lds_w0 = 0) {
     ChainState st;
     st.out_id = st.p1_id = 0xFFFF;
     st.out.X = st.out.Y = st.out.Z = st.p1.X = st.p1.Y = st.p1.Z = u256_zero();
-    st.acc = continue_prefix ? range_product(B, i, lo - 1) : u256_small(1);
-    for (int t = lo; t < hi; t++) body_chain_op(G, B, i, t, table_affine, st, lds_fb, lds_w0);
+    st.acc = continue_prefix ? range_product<CV>(B, i, lo - 1) : u256_small(1);
+    for (int t = lo; t < hi; t++) body_chain_op<CV, GENERIC>(G, B, i, t, table_affine, st, lds_fb, lds_w0);
 }
 
 // Ops lo + row + j * rows (j < count) of a piece whose `rows` interleaved sub-chains do not depend on each other.
@@ -417,11 +430,13 @@ P2E_HD void body_verify_check(const Program& G, const Buffers& B, size_t i) {
 // whose prefix products are already in PREF (the normal case); otherwise the forward pass runs here.
 // uniform_t: every lane of the wave walks the same ops (so the descriptor can be a scalar load); false when lanes own
 // different sub-ranges (body_batch_inv_split)
+template <class CV = Secp256k1>
 P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0, int t1, bool have_prefix, bool uniform_t = true) {
     (void)G;
+    typedef typename CV::Fp F;
     U256 acc;
     if (have_prefix) {
-        acc = range_product(B, i, t1 - 1);
+        acc = range_product<CV>(B, i, t1 - 1);
     } else {
         acc = u256_small(1);
         for (int t = t0; t < t1; t++) {
@@ -429,63 +444,63 @@ P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0,
             U256 z = B.PZ[o];
             if (u256_is_zero(z)) z = u256_small(1);   // flagged by phase A
             B.PREF[o] = acc;
-            acc = fp_mul(acc, z);
+            acc = fe_mul<F>(acc, z);
         }
     }
-    U256 inv = fe_inv<ModP>(acc);
+    U256 inv = fe_inv<F>(acc);
     for (int t = t1 - 1; t >= t0; t--) {
         size_t o = (size_t)t * B.n + i;
         U256 z = B.PZ[o];
         if (u256_is_zero(z)) z = u256_small(1);
-        U256 zi = fp_mul(inv, B.PREF[o]);
-        inv = fp_mul(inv, z);
-        B.PW[o] = fp_mul(B.PW[o], zi);  // v^-1 of op t
+        U256 zi = fe_mul<F>(inv, B.PREF[o]);
+        inv = fe_mul<F>(inv, z);
+        B.PW[o] = fe_mul<F>(B.PW[o], zi);  // v^-1 of op t
         const uint8_t flags = uniform_t ? load_op(B.ops, t).flags : B.ops[t].flags;
         if (!(flags & F_NO_AFFINE)) {
-            U256 zi2 = fp_sqr(zi);
-            U256 zi3 = fp_mul(zi2, zi);
-            B.AX[o] = fp_mul(B.PX[o], zi2);
-            B.AY[o] = fp_mul(B.PY[o], zi3);
+            U256 zi2 = fe_sqr<F>(zi);
+            U256 zi3 = fe_mul<F>(zi2, zi);
+            B.AX[o] = fe_mul<F>(B.PX[o], zi2);
+            B.AY[o] = fe_mul<F>(B.PY[o], zi3);
         }
     }
 }
 
 // ---- phase C: witness columns of one curve op ---------------------------------------------------------------
 // gadgets/curve.rs:202-223
-template <class E>
+template <class E, class CV = Secp256k1>
 P2E_HD Aff wit_curve_add(E& e, const Aff& p1, const Aff& p2, const U256& vinv, uint8_t& err) {
-    U256 u = wit_sub<ModP>(e, p2.y, p1.y);
-    U256 v = wit_sub<ModP>(e, p2.x, p1.x);
-    wit_inv_given<ModP>(e, v, vinv, err);
-    U256 s = wit_mul<ModP>(e, u, vinv, err);
-    U256 s2 = wit_mul<ModP>(e, s, s, err);
-    U256 xs = wit_add<ModP>(e, p2.x, p1.x);
+    U256 u = wit_sub<typename CV::Fp>(e, p2.y, p1.y);
+    U256 v = wit_sub<typename CV::Fp>(e, p2.x, p1.x);
+    wit_inv_given<typename CV::Fp>(e, v, vinv, err);
+    U256 s = wit_mul<typename CV::Fp>(e, u, vinv, err);
+    U256 s2 = wit_mul<typename CV::Fp>(e, s, s, err);
+    U256 xs = wit_add<typename CV::Fp>(e, p2.x, p1.x);
     Aff r;
-    r.x = wit_sub<ModP>(e, s2, xs);
-    U256 xd = wit_sub<ModP>(e, p1.x, r.x);
-    U256 pr = wit_mul<ModP>(e, s, xd, err);
-    r.y = wit_sub<ModP>(e, pr, p1.y);
+    r.x = wit_sub<typename CV::Fp>(e, s2, xs);
+    U256 xd = wit_sub<typename CV::Fp>(e, p1.x, r.x);
+    U256 pr = wit_mul<typename CV::Fp>(e, s, xd, err);
+    r.y = wit_sub<typename CV::Fp>(e, pr, p1.y);
     return r;
 }
 // gadgets/curve.rs:160-185
-template <class E>
+template <class E, class CV = Secp256k1>
 P2E_HD Aff wit_curve_double(E& e, const Aff& p, const U256& vinv, uint8_t& err) {
-    U256 dy = wit_add<ModP>(e, p.y, p.y);
-    wit_inv_given<ModP>(e, dy, vinv, err);
-    U256 xx = wit_mul<ModP>(e, p.x, p.x, err);
-    U256 summ[4] = {xx, xx, xx, u256_zero()};
-    U256 t = wit_add_many<ModP, 4>(e, summ);
-    U256 l = wit_mul<ModP>(e, t, vinv, err);
-    U256 l2 = wit_mul<ModP>(e, l, l, err);
-    U256 xd2 = wit_add<ModP>(e, p.x, p.x);
+    U256 dy = wit_add<typename CV::Fp>(e, p.y, p.y);
+    wit_inv_given<typename CV::Fp>(e, dy, vinv, err);
+    U256 xx = wit_mul<typename CV::Fp>(e, p.x, p.x, err);
+    U256 summ[4] = {xx, xx, xx, CV::a()};
+    U256 t = wit_add_many<typename CV::Fp, 4>(e, summ);
+    U256 l = wit_mul<typename CV::Fp>(e, t, vinv, err);
+    U256 l2 = wit_mul<typename CV::Fp>(e, l, l, err);
+    U256 xd2 = wit_add<typename CV::Fp>(e, p.x, p.x);
     Aff r;
-    r.x = wit_sub<ModP>(e, l2, xd2);
-    U256 xdf = wit_sub<ModP>(e, p.x, r.x);
-    U256 lx = wit_mul<ModP>(e, l, xdf, err);
-    r.y = wit_sub<ModP>(e, lx, p.y);
+    r.x = wit_sub<typename CV::Fp>(e, l2, xd2);
+    U256 xdf = wit_sub<typename CV::Fp>(e, p.x, r.x);
+    U256 lx = wit_mul<typename CV::Fp>(e, l, xdf, err);
+    r.y = wit_sub<typename CV::Fp>(e, lx, p.y);
     return r;
 }
-template <class E>
+template <class E, class CV = Secp256k1>
 P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t, const Aff* lds_fb = nullptr) {
     const OpDesc op = load_op(B.ops, t);
     uint8_t err = 0;
@@ -496,16 +511,16 @@ P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t, con
     U256 vinv = B.PW[(size_t)t * B.n + i];
     Aff p1 = load_aff_src(B, i, s1);
     if (op.kind == OP_DBL) {
-        (void)wit_curve_double(e, p1, vinv, err);
+        (void)wit_curve_double<E, CV>(e, p1, vinv, err);
     } else {
         Aff p2 = (s2 & SRC_FB_BIT) ? (lds_fb ? lds_fb[s2 & 15u] : B.fbtab[s2 & SRC_ID_MASK]) : load_aff_src(B, i, (uint16_t)(s2 & (DYN_CONST_BIT | SRC_ID_MASK)));
         const bool sel = (s2 & SRC_SEL_BIT) != 0;
-        Aff s = wit_curve_add(e, p1, p2, vinv, err);
+        Aff s = wit_curve_add<E, CV>(e, p1, p2, vinv, err);
         if (op.kind == OP_CADD) {  // gadgets/curve.rs:225-243: sum always computed (Q7), then selected
             bool b = sel;
             const U256 z = u256_zero();
-            (void)wit_add<ModP>(e, u256_select(b, s.x, z), u256_select(b, z, p1.x));
-            (void)wit_add<ModP>(e, u256_select(b, s.y, z), u256_select(b, z, p1.y));
+            (void)wit_add<typename CV::Fp>(e, u256_select(b, s.x, z), u256_select(b, z, p1.x));
+            (void)wit_add<typename CV::Fp>(e, u256_select(b, s.y, z), u256_select(b, z, p1.y));
         }
         if (op.flags & F_CHECK_R) {  // gadgets/ecdsa.rs:48-52 connect_nonnative(r, point.x)
             U256 r = load_packed(B.r, i);

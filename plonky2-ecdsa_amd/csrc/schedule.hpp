@@ -14,6 +14,10 @@
 //   gadgets/curve_msm.rs:21       curve_msm_circuit
 //   gadgets/glv.rs:26-44          decompose_secp256k1_scalar / glv_mul
 //   gadgets/ecdsa.rs:30           verify_secp256k1_message_circuit
+// and, for the curve programs of curves.hpp:
+//   gadgets/curve.rs:137-147,245-285          curve_neg / curve_scalar_mul
+//   gadgets/curve_windowed_mul.rs:52-72,131-173  precompute_window / curve_scalar_mul_windowed
+//   gadgets/ecdsa.rs:55-78                    verify_p256_message_circuit
 #pragma once
 #include <cassert>
 #include <string>
@@ -23,6 +27,7 @@
 #include "consts.hpp"
 #include "ux.hpp"
 #include "pipeline.hpp"
+#include "curves.hpp"
 
 namespace p2e {
 namespace host {
@@ -104,10 +109,10 @@ public:
         return {a.field, gen(GEN_INV, a.field, 18, {a}, range_check), NL};
     }
     NonNativeTarget constant_nonnative(int field, u32 const_id) {   // constant_biguint: convert_base's limb count (Q5)
-        return {field, AUX_SRC_CONST | const_id, const_num_limbs(const_value(const_id))};
+        return {field, AUX_SRC_CONST | const_id, const_num_limbs(cval(const_id))};
     }
     NonNativeTarget neg_nonnative(NonNativeTarget a, bool range_check = false) {   // gadgets/nonnative.rs:491-500
-        return sub_nonnative(constant_nonnative(a.field, CONSTV_ZERO), a, range_check);
+        return sub_nonnative(constant_nonnative(a.field, id_zero_), a, range_check);
     }
     // gadgets/nonnative.rs:584-596: not(b), neg, neg * b, x * not_b, add
     NonNativeTarget nonnative_conditional_neg(NonNativeTarget x, BoolTarget b, bool range_check = false) {
@@ -148,7 +153,7 @@ public:
     void curve_assert_valid(const AffinePointTarget& p) {   // gadgets/curve.rs:123-135
         Scope s(this, "assert_valid");
         const NonNativeTarget x = x_of(p), y = y_of(p);
-        const NonNativeTarget a = constant_nonnative(FIELD_BASE, CONSTV_ZERO), b = constant_nonnative(FIELD_BASE, CONSTV_B7);
+        const NonNativeTarget a = constant_nonnative(FIELD_BASE, id_a_), b = constant_nonnative(FIELD_BASE, id_b_);
         mul_nonnative(y, y, true);
         NonNativeTarget x2 = mul_nonnative(x, x);
         NonNativeTarget x3 = mul_nonnative(x2, x);
@@ -170,16 +175,14 @@ public:
         return curve_op(OP_CADD, p1, p2, range_check, not_b_aux);
     }
     AffinePointTarget constant_affine_point(int which) {
-        const Consts& C = consts();
-        (void)C;
         return {make_ref(R_CONST, (u32)which), true, AUX_SRC_CONST | (u32)(2 * which), AUX_SRC_CONST | (u32)(2 * which + 1),
-                const_num_limbs(const_value((u32)(2 * which))), const_num_limbs(const_value((u32)(2 * which + 1)))};
+                const_num_limbs(cval((u32)(2 * which))), const_num_limbs(cval((u32)(2 * which + 1)))};
     }
 
     // ---- fixed_base_curve_mul_circuit(builder, G, scalar) ----
     AffinePointTarget fixed_base_curve_mul_circuit(NonNativeTarget scalar) {
         split_nonnative_to_4_bit_limbs(scalar);
-        AffinePointTarget result = constant_affine_point(CONST_RANDO);
+        AffinePointTarget result = constant_affine_point(id_rando_);
         for (int w = 0; w < FB_WINDOWS; w++) {
             Scope s(this, "win" + std::to_string(w));
             // is_equal(limb, zero), not, random_access_curve_points(limb, muls_point), curve_conditional_add
@@ -198,7 +201,153 @@ public:
             aux(it, 2 + 2 * NL + 1 + 2 * NL + (u32)it.nlx + (u32)it.nly);
         }
         Scope s(this, "unblind");
-        return curve_add(result, constant_affine_point(CONST_NEG_RANDO), true);
+        return curve_add(result, constant_affine_point(id_neg_rando_), true);
+    }
+
+    // ---- curve programs (curves.hpp) -----------------------------------------------------------------------
+    // Constants of a curve program live in the builder: points gpts[c] (source codes 2c / 2c + 1 as for the built-in
+    // ones), scalar constants gvals[j] (source code 0x8000 + j), the fixed-base table gfbtab of the curve's generator.
+    std::vector<Aff> gpts, gfbtab;
+    std::vector<U256> gvals;
+    void begin_curve_program(int kind, const U256& a, const U256& b) {
+        generic_ = true;
+        prog.cp_kind = kind;
+        id_zero_ = add_const_value(u256_zero());
+        id_a_ = add_const_value(a);
+        id_b_ = add_const_value(b);
+    }
+    u32 add_const_point(const Aff& a) {
+        gpts.push_back(a);
+        return (u32)gpts.size() - 1;
+    }
+    u32 add_const_value(const U256& v) {
+        gvals.push_back(v);
+        return 0x8000u + (u32)gvals.size() - 1;
+    }
+    // the value behind AUX_SRC_CONST | id in THIS builder's program
+    U256 cval(u32 id) const {
+        if (!generic_) return const_value(id);
+        if (id >= 0x8000u) return gvals[id - 0x8000u];
+        return (id & 1) ? gpts[id >> 1].y : gpts[id >> 1].x;
+    }
+    // curve_neg of a CONSTANT point (gadgets/curve.rs:137-147): neg_nonnative(y) is a subtraction generator (10 columns,
+    // filled by the scalar phase); the GPU reads the negated point itself from constant `which_negated`
+    AffinePointTarget curve_neg_const(u32 which, u32 which_negated) {
+        AffinePointTarget p = constant_affine_point((int)which);
+        prog.cp_neg_col = (int32_t)col_;
+        prog.cp_neg_const = (int32_t)which;
+        NonNativeTarget ny = neg_nonnative(y_of(p));
+        AffinePointTarget q = constant_affine_point((int)which_negated);
+        q.xcol = p.xcol;
+        q.nlx = p.nlx;
+        q.ycol = ny.col;
+        q.nly = NL;
+        return q;
+    }
+    // gadgets/curve_windowed_mul.rs:52-72; g / neg_g: the rand() point and its negative (program constants)
+    void precompute_window(const AffinePointTarget& p, u32 g, u32 neg_g, AffinePointTarget* multiples /*16*/) {
+        AffinePointTarget neg = constant_affine_point((int)neg_g);
+        multiples[0] = constant_affine_point((int)g);
+        for (int i = 1; i < 16; i++) multiples[i] = curve_add(p, multiples[i - 1], true);
+        for (int i = 1; i < 16; i++) multiples[i] = curve_add(neg, multiples[i], true);
+    }
+    // gadgets/curve_windowed_mul.rs:131-173.  Constants: g, -g, starting_point, 2^264 starting_point and its negative
+    AffinePointTarget curve_scalar_mul_windowed(const AffinePointTarget& p, NonNativeTarget n, u32 g, u32 neg_g, u32 start, u32 spm,
+                                                u32 neg_spm, bool range_check) {
+        split_nonnative_to_4_bit_limbs(n);
+        AffinePointTarget result = constant_affine_point((int)start);
+        AffinePointTarget pre[16];
+        {
+            Scope s(this, "precompute");
+            const int t0 = (int)ops.size();
+            precompute_window(p, g, neg_g, pre);
+            prog.cp_table_ops = (int32_t)ops.size() - t0;
+        }
+        for (int i = 0; i < 16; i++) prog.msm_tab[i] = pre[i].ref;
+        prog.cp_rows = CP_WINDOWS;
+        for (int w = CP_WINDOWS - 1; w >= 0; w--) {
+            Scope s(this, "window" + std::to_string(w));
+            result = curve_repeated_double(result, 4, false);
+            // aux columns of this window: [selected x (9), selected y (9), is_zero, should_add, not_b, sum.x*b (9),
+            // sum.y*b (9), p1.x*not_b, p1.y*not_b]  (random_access first, then is_equal / not: :160-163)
+            const u32 base = aux_col_;
+            AffinePointTarget r{make_ref(R_MSMTAB, (u32)w), false, AUX_SRC_AUX | base, AUX_SRC_AUX | (base + NL)};
+            const u32 nlx = (u32)result.nlx, nly = (u32)result.nly;
+            result = curve_conditional_add(result, r, base + 2 * NL + 2, false);
+            aux_skip(AUX_KIND_CP_WINDOW, 2 * NL + 2 + 1 + 2 * NL + nlx + nly);
+        }
+        Scope s(this, "unblind");
+        AffinePointTarget to_add = curve_neg_const(spm, neg_spm);
+        return curve_add(result, to_add, range_check);
+    }
+    // gadgets/curve.rs:245-285.  Constants: rando (the rand() point) and its negative
+    AffinePointTarget curve_scalar_mul(const AffinePointTarget& p, NonNativeTarget n, u32 rando, u32 neg_rando, bool range_check) {
+        assert(n.nl == NL);
+        aux_skip(AUX_KIND_CP_BITS, (u32)n.nl * BITS);   // split_nonnative_to_bits gadgets/nonnative.rs:566-582
+        // result: a virtual point connected to the constant (9-limb targets that carry the constant's limbs)
+        AffinePointTarget result = constant_affine_point((int)rando);
+        result.nlx = result.nly = NL;
+        AffinePointTarget tp = p;
+        prog.cp_rows = CP_BITS;
+        for (int i = 0; i < CP_BITS; i++) {
+            Scope s(this, "bit" + std::to_string(i));
+            // aux columns of this bit: [not_bit, sum.x*bit (9), result.x*not_bit (9), sum.y*bit (9), result.y*not_bit (9)]
+            const u32 base = aux_col_;
+            AffinePointTarget sel = tp;
+            assert(ref_kind(tp.ref) == R_SLOT);
+            const u32 slot = ref_id(tp.ref) == SLOT_P_PLACEHOLDER ? 0xFFFu : ref_id(tp.ref);
+            assert(slot <= 0xFFFu);
+            sel.ref = make_ref(R_SELSLOT, slot | ((u32)i << 12));
+            result = curve_op(OP_CADD, result, sel, false, base, 1);
+            aux_skip(AUX_KIND_CP_BIT, 1 + 4 * NL);
+            tp = curve_double(tp, false);
+        }
+        Scope s(this, "unblind");
+        AffinePointTarget neg_r = curve_neg_const(rando, neg_rando);
+        return curve_add(result, neg_r, range_check);
+    }
+    // the caller's point of a curve program: 9-limb virtual targets set by value
+    AffinePointTarget input_point() { return {make_ref(R_SLOT, SLOT_P_PLACEHOLDER), true, AUX_SRC_INPUT | INPUT_PX, AUX_SRC_INPUT_PY}; }
+    // stand-alone gadget circuits: point in (px, py), scalar in the msg slot
+    void windowed_mul_circuit(u32 g, u32 neg_g, u32 start, u32 spm, u32 neg_spm) {
+        curve_scalar_mul_windowed(input_point(), NonNativeTarget{FIELD_SCALAR, AUX_SRC_INPUT | INPUT_MSG, NL}, g, neg_g, start, spm, neg_spm, true);
+        finish_curve_program();
+    }
+    void scalar_mul_circuit(u32 rando, u32 neg_rando) {
+        curve_scalar_mul(input_point(), NonNativeTarget{FIELD_SCALAR, AUX_SRC_INPUT | INPUT_MSG, NL}, rando, neg_rando, true);
+        finish_curve_program();
+    }
+    // gadgets/ecdsa.rs:55-78
+    void verify_p256_message_circuit(u32 rando32, u32 neg_rando32, u32 g, u32 neg_g, u32 start, u32 spm, u32 neg_spm) {
+        prog.full_verify = 1;
+        id_rando_ = rando32;
+        id_neg_rando_ = neg_rando32;
+        prog.sc.assert_valid = (int32_t)col_;
+        AffinePointTarget pk = input_point();
+        curve_assert_valid(pk);
+        NonNativeTarget s{FIELD_SCALAR, AUX_SRC_INPUT | INPUT_S, NL}, msg{FIELD_SCALAR, AUX_SRC_INPUT | INPUT_MSG, NL},
+            r{FIELD_SCALAR, AUX_SRC_INPUT | INPUT_R, NL};
+        prog.sc.inv_s = (int32_t)col_;
+        NonNativeTarget c = inv_nonnative(s);
+        prog.sc.u1 = (int32_t)col_;
+        NonNativeTarget u1 = mul_nonnative(msg, c, true);
+        prog.sc.u2 = (int32_t)col_;
+        NonNativeTarget u2 = mul_nonnative(r, c, true);
+        AffinePointTarget point1, point2;
+        {
+            Scope sc(this, "fixed_base");
+            point1 = fixed_base_curve_mul_circuit(u1);
+        }
+        {
+            Scope sc(this, "windowed_mul");
+            point2 = curve_scalar_mul_windowed(pk, u2, g, neg_g, start, spm, neg_spm, true);
+        }
+        {
+            Scope sc(this, "final_add");
+            curve_add(point1, point2, true);
+            ops.back().flags |= F_CHECK_R;
+        }
+        finish_curve_program();
     }
 
     // ---- curve_msm_circuit(builder, p, q, n, m) ----
@@ -354,9 +503,29 @@ public:
         }
     }
 
+    static constexpr int AUX_KIND_CP_WINDOW = 16, AUX_KIND_CP_BITS = 17, AUX_KIND_CP_BIT = 18;   // p2e_aux_desc kinds (no k_aux pass yet)
 private:
     static constexpr u32 SLOT_P_PLACEHOLDER = 0xFFFF00, SLOT_SP_PLACEHOLDER = 0xFFFF01;
     u32 col_ = 0, aux_col_ = 0, split4_col_ = 0;
+    bool generic_ = false;
+    u32 id_zero_ = CONSTV_ZERO, id_a_ = CONSTV_ZERO, id_b_ = CONSTV_B7;
+    int id_rando_ = CONST_RANDO, id_neg_rando_ = CONST_NEG_RANDO;
+    // built-in-generator values a curve program's gadgets create: numbered (the operand wiring refers to them) and
+    // described, but no AuxItem: the k_aux pass covers the two built-in programs only
+    void aux_skip(int kind, u32 ncols) {
+        aux_gens.push_back({kind, aux_col_, ncols, label()});
+        aux_col_ += ncols;
+    }
+    void finish_curve_program() {
+        prog.num_chains = 1;
+        prog.chain_begin[0] = 0;
+        prog.chain_end[0] = (int)ops.size();
+        prog.msm_loop_begin = prog.msm_loop_iters = 0;
+        finish();
+        for (auto& o : ops)
+            if (ref_kind(o.ref2) == R_SELSLOT && (ref_id(o.ref2) & 0xFFFu) == 0xFFFu)
+                o.ref2 = make_ref(R_SELSLOT, (ref_id(o.ref2) & ~0xFFFu) | (u32)prog.slot_p);
+    }
     int num_cadd_ = 0;
     NonNativeTarget glv_k1_{FIELD_SCALAR}, glv_k2_{FIELD_SCALAR};
     BoolTarget glv_k1_neg_{0}, glv_k2_neg_{0};
@@ -424,7 +593,10 @@ private:
         while (n > 0 && l[n - 1] == 0) n--;
         return n;
     }
-    AffinePointTarget curve_op(OpKind kind, AffinePointTarget p1, AffinePointTarget p2, bool range_check, u32 not_b_aux = 0) {
+    // sel_layout (conditional adds): order of the four bool products behind not_b -- 0: sum.x, sum.y, p1.x, p1.y
+    // (curve_conditional_add gadgets/curve.rs:234-238), 1: sum.x, p1.x, sum.y, p1.y (curve_scalar_mul :262-265)
+    AffinePointTarget curve_op(OpKind kind, AffinePointTarget p1, AffinePointTarget p2, bool range_check, u32 not_b_aux = 0,
+                               int sel_layout = 0) {
         OpDesc d{};
         d.kind = kind;
         d.flags = (uint8_t)((p1.z_one ? F_Z1ONE : 0) | ((kind != OP_DBL && p2.z_one) ? F_Z2ONE : 0));
@@ -438,7 +610,7 @@ private:
             NonNativeTarget dy = add_nonnative(y1, y1);
             NonNativeTarget idy = inv_nonnative(dy);
             NonNativeTarget xx = mul_nonnative(x1, x1);
-            NonNativeTarget tr = add_many_nonnative({xx, xx, xx, constant_nonnative(FIELD_BASE, CONSTV_ZERO)});
+            NonNativeTarget tr = add_many_nonnative({xx, xx, xx, constant_nonnative(FIELD_BASE, id_a_)});
             NonNativeTarget lam = mul_nonnative(tr, idy);
             NonNativeTarget lam2 = mul_nonnative(lam, lam);
             NonNativeTarget xd = add_nonnative(x1, x1);
@@ -459,7 +631,12 @@ private:
             NonNativeTarget pr = mul_nonnative(sl, xd);
             y3 = sub_nonnative(pr, y1, rc);
             if (kind == OP_CADD) {  // ... then selects: add(sum.x * b, p1.x * not_b), add(sum.y * b, p1.y * not_b)  :234-240
-                const u32 xt = not_b_aux + 1, yt = xt + NL, xf = yt + NL, yf = xf + (u32)p1.nlx;
+                u32 xt = not_b_aux + 1, yt = xt + NL, xf = yt + NL, yf = xf + (u32)p1.nlx;
+                if (sel_layout == 1) {
+                    xf = xt + NL;
+                    yt = xf + (u32)p1.nlx;
+                    yf = yt + NL;
+                }
                 const int F = FIELD_BASE;
                 add_nonnative({F, AUX_SRC_AUX | xt, NL}, {F, AUX_SRC_AUX | xf, p1.nlx}, range_check);
                 add_nonnative({F, AUX_SRC_AUX | yt, NL}, {F, AUX_SRC_AUX | yf, p1.nly}, range_check);

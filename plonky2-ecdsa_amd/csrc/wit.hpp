@@ -385,14 +385,12 @@ P2E_HD U256 wit_inv(E& e, const U256& x_raw, uint8_t& err) {
 // ---- mul + checksum ---------------------------------------------------------------------------------
 // un-carried q*m convolution column i, exploiting m29[j] = (2^29-1) - d[j] for p
 template <class MOD>
-P2E_HD u64 qm_column(const u32* q29, int i);
-template <>
-P2E_HD u64 qm_column<ModN>(const u32* q29, int i) {
+P2E_HD u64 qm_column(const u32* q29, int i) {
     u64 acc = 0;
     P2E_UNROLL
     for (int j = 0; j < NL; j++) {
         int k = i - j;
-        if (k >= 0 && k < NL) acc += (u64)q29[k] * ModN::m29(j);
+        if (k >= 0 && k < NL) acc += (u64)q29[k] * MOD::m29(j);
     }
     return acc;
 }

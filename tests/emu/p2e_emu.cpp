@@ -11,6 +11,7 @@
 #include "../../plonky2-ecdsa_amd/csrc/prims.hpp"
 #include "../../plonky2-ecdsa_amd/csrc/quad.hpp"
 #include "../../plonky2-ecdsa_amd/csrc/schedule.hpp"
+#include "../../plonky2-ecdsa_amd/csrc/curve_program.hpp"
 
 using namespace p2e;
 
@@ -400,4 +401,126 @@ long emu_split(const uint8_t* packed, u64* limbs, size_t n, size_t ld) {
     return 0;
 }
 long emu_pack(const u64* limbs, uint8_t* packed, size_t n, size_t ld, uint8_t* err) { LOOP(prim_pack(limbs, packed, ld, i)) }
+}
+
+// ---- curve programs (curves.hpp): the bodies kc_scalar / kc_chains / kc_batch_inv / kc_expand run, in the piece order
+// of run_curve_program (pieces of `piece` ops, the per-signature table as its own piece and affine afterwards) --------
+template <class CV>
+static long run_curve(const host::CurveProgramHost& H, const uint8_t* msg, const uint8_t* r, const uint8_t* s, const uint8_t* pkx,
+                      const uint8_t* pky, uint64_t* cols, size_t n, size_t ld, uint8_t* err, uint8_t* valid, int piece) {
+    const host::ScheduleBuilder& sb = H.sb;
+    const Program& G = sb.prog;
+    const size_t rows = (size_t)(G.cp_rows > MSM_DIGITS ? G.cp_rows : MSM_DIGITS);
+    std::vector<U256> PX((size_t)G.num_slots * n), PY((size_t)G.num_slots * n), PZ((size_t)G.num_slots * n),
+        PW((size_t)G.num_ops * n), PREF((size_t)G.num_ops * n), AX((size_t)G.num_slots * n), AY((size_t)G.num_slots * n);
+    std::vector<uint8_t> dig4((size_t)FB_WINDOWS * n), dig2(rows * n), valid8(n);
+    std::vector<uint16_t> dyn((size_t)G.num_cadd * n + 1), src((size_t)G.num_ops * 2 * n), msrc(rows * n);
+    std::vector<u32> err32(n);
+    Buffers B{};
+    B.msg = msg; B.r = r; B.s = s; B.pkx = pkx; B.pky = pky;
+    B.sink = Sink{cols, ld, nullptr, 0, nullptr, 0, nullptr};
+    B.n = n;
+    B.err = err32.data(); B.valid = valid8.data();
+    B.PX = PX.data(); B.PY = PY.data(); B.PZ = PZ.data(); B.PW = PW.data(); B.PREF = PREF.data();
+    B.AX = AX.data(); B.AY = AY.data();
+    B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data(); B.src = src.data(); B.msrc = msrc.data();
+    B.cpts = sb.gpts.data(); B.fbtab = sb.gfbtab.data(); B.ops = sb.ops.data();
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)n; i++) body_cscalar<CV, Emit>(G, B, (size_t)i);
+    int tb = -1, te = -1;
+    if (G.cp_table_ops > 0) {
+        te = 0;
+        for (int k = 1; k < 16; k++) te = std::max(te, (int)ref_id(G.msm_tab[k]) + 1);
+        tb = te - G.cp_table_ops;
+    }
+    bool table_done = false;
+    auto run_piece = [&](int lo, int hi, bool table) {
+#pragma omp parallel for
+        for (long long i = 0; i < (long long)n; i++) {
+            body_chain_range<CV, true>(G, B, (size_t)i, lo, hi, table_done, false);
+            body_batch_inv<CV>(G, B, (size_t)i, lo, hi, true);
+            for (int t = lo; t < hi; t++) body_expand<Emit, CV>(G, B, (size_t)i, t);
+        }
+        if (table) table_done = true;
+    };
+    auto cut = [&](int lo, int hi, bool table) {
+        if (table) {
+            run_piece(lo, hi, true);
+            return;
+        }
+        for (int a = lo; a < hi; a += piece) run_piece(a, a + piece < hi ? a + piece : hi, false);
+    };
+    if (tb >= 0) {
+        cut(0, tb, false);
+        cut(tb, te, true);
+        cut(te, G.num_ops, false);
+    } else {
+        cut(0, G.num_ops, false);
+    }
+    long bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        err[i] = (uint8_t)err32[i];
+        valid[i] = err32[i] ? 0 : valid8[i];
+        bad += err32[i] != 0;
+    }
+    return bad;
+}
+extern "C" {
+// kind / curve: include/p2e.h P2E_CP_* / P2E_CURVE_*; blind: the gadget's rand() point.  Returns the flagged count, or
+// -1 for an unknown program; *num_cols receives the program's column count (call with n = 0 to query it).
+long emu_curve_program(int kind, int curve, const uint8_t* blind_x, const uint8_t* blind_y, const uint8_t* msg, const uint8_t* r,
+                       const uint8_t* s, const uint8_t* pkx, const uint8_t* pky, uint64_t* cols, size_t n, size_t ld, uint8_t* err,
+                       uint8_t* valid, int piece, long* num_cols, long* num_gens, long* num_aux) {
+    Aff blind;
+    memcpy(blind.x.w, blind_x, 32);
+    memcpy(blind.y.w, blind_y, 32);
+    host::CurveProgramHost H;
+    if (!host::make_curve_program(H, kind, curve, blind)) return -1;
+    if (num_cols) *num_cols = H.sb.prog.num_cols;
+    if (num_gens) *num_gens = (long)H.sb.gens.size();
+    if (num_aux) *num_aux = (long)H.sb.aux_tab.num_aux_cols;
+    if (n == 0) return 0;
+    if (piece < 1) piece = 32;
+    if (curve == 1) return run_curve<P256>(H, msg, r, s, pkx, pky, cols, n, ld, err, valid, piece);
+    return run_curve<Secp256k1>(H, msg, r, s, pkx, pky, cols, n, ld, err, valid, piece);
+}
+// generator table (kind, field, first column, column count) and operand wiring of a curve program, for the host tests
+long emu_curve_program_gens(int kind, int curve, const uint8_t* blind_x, const uint8_t* blind_y, int32_t* kinds, int32_t* fields,
+                            uint32_t* first, uint32_t* ncols, uint32_t* src /*[4 per gen]*/, uint8_t* nl /*[4 per gen]*/, size_t cap) {
+    Aff blind;
+    memcpy(blind.x.w, blind_x, 32);
+    memcpy(blind.y.w, blind_y, 32);
+    host::CurveProgramHost H;
+    if (!host::make_curve_program(H, kind, curve, blind)) return -1;
+    const auto& g = H.sb.gens;
+    for (size_t k = 0; k < g.size() && k < cap; k++) {
+        kinds[k] = g[k].kind;
+        fields[k] = g[k].field;
+        first[k] = g[k].col;
+        ncols[k] = g[k].ncols;
+        for (int j = 0; j < 4; j++) {
+            src[4 * k + j] = g[k].src[j];
+            nl[4 * k + j] = g[k].nl[j];
+        }
+    }
+    return (long)g.size();
+}
+int emu_synth_signatures_curve(int curve, uint64_t seed, size_t first, size_t n, uint8_t* msg32, uint8_t* r32, uint8_t* s32,
+                               uint8_t* pkx32, uint8_t* pky32) {
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)n; i++) {
+        U256 msg, r, s;
+        Aff pk;
+        if (curve == 1)
+            host::synth_signature_cv<P256>(seed, first + (u64)i, msg, r, s, pk);
+        else
+            host::synth_signature_cv<Secp256k1>(seed, first + (u64)i, msg, r, s, pk);
+        memcpy(msg32 + 32 * i, msg.w, 32);
+        memcpy(r32 + 32 * i, r.w, 32);
+        memcpy(s32 + 32 * i, s.w, 32);
+        memcpy(pkx32 + 32 * i, pk.x.w, 32);
+        memcpy(pky32 + 32 * i, pk.y.w, 32);
+    }
+    return 0;
+}
 }
