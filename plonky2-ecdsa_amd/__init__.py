@@ -45,6 +45,10 @@ GLV_MUL_UX_COLS = 194361
 VERIFY_GATE_COLS = 10703    # gate-internal values of the built-in gates (include/p2e.h p2e_gate_internal_batch)
 GLV_MUL_GATE_COLS = 5621
 PROGRAM_VERIFY, PROGRAM_GLV_MUL = 0, 1
+# curve programs (include/p2e.h P2E_CURVE_* / P2E_CP_*)
+CURVE_SECP256K1, CURVE_P256 = 0, 1
+CP_WINDOWED_MUL, CP_SCALAR_MUL, CP_VERIFY = 1, 2, 3
+WINDOWED_MUL_COLS, SCALAR_MUL_COLS, P256_VERIFY_COLS = 98185, 139354, 115557
 
 # every symbol include/p2e.h declares
 EXPORTS = (
@@ -57,6 +61,9 @@ EXPORTS = (
     "p2e_schedule_num_cols", "p2e_synth_signatures", "p2e_aux_witness_batch", "p2e_aux_describe", "p2e_aux_num_cols",
     "p2e_compact_layout", "p2e_columns_compact", "p2e_ecdsa_verify_witness_compact_batch",
     "p2e_glv_mul_witness_compact_batch", "p2e_aux_witness_compact_batch", "p2e_compact_to_rows", "p2e_ecdsa_verify_batch", "p2e_biguint_div_rem_batch",
+    "p2e_curve_program_create", "p2e_curve_program_destroy", "p2e_curve_program_num_cols", "p2e_curve_program_num_aux_cols",
+    "p2e_curve_program_scratch_bytes", "p2e_curve_program_describe", "p2e_curve_program_wiring", "p2e_curve_program_aux_describe",
+    "p2e_curve_program_const", "p2e_curve_mul_witness_batch", "p2e_p256_verify_witness_batch", "p2e_synth_signatures_curve",
 )
 
 
@@ -110,8 +117,11 @@ def lib():
         for name in EXPORTS:
             if name.endswith("_batch") or name in ("p2e_limb_split", "p2e_limb_pack", "p2e_columns_to_rows", "p2e_schedule_describe",
                                                    "p2e_schedule_num_cols", "p2e_aux_describe", "p2e_aux_num_cols", "p2e_compact_layout",
-                                                   "p2e_columns_compact", "p2e_compact_to_rows"):
+                                                   "p2e_columns_compact", "p2e_compact_to_rows", "p2e_curve_program_num_cols",
+                                                   "p2e_curve_program_num_aux_cols", "p2e_curve_program_describe",
+                                                   "p2e_curve_program_wiring", "p2e_curve_program_aux_describe"):
                 getattr(_lib, name).restype = C.c_long
+        _lib.p2e_curve_program_scratch_bytes.restype = C.c_size_t
     return _lib
 
 
@@ -255,6 +265,102 @@ def synth_signatures(seed: int, n: int, first: int = 0):
     if rc:
         raise P2EError("p2e_synth_signatures failed")
     return out
+
+
+def synth_signatures_curve(curve: int, seed: int, n: int, first: int = 0):
+    """Valid signatures on a curve of the crate (CURVE_*): (msg, r, s, pk.x, pk.y) as five (n, 32) uint8 arrays (host)."""
+    out = [np.zeros((n, 32), dtype=np.uint8) for _ in range(5)]
+    rc = lib().p2e_synth_signatures_curve(C.c_int(curve), C.c_uint64(seed), C.c_size_t(first), C.c_size_t(n), *[_ptr(a) for a in out])
+    if rc:
+        raise P2EError("p2e_synth_signatures_curve failed")
+    return out
+
+
+class CurveProgram:
+    """One built circuit of curve_scalar_mul_windowed / curve_scalar_mul / verify_p256_message_circuit
+    (gadgets/curve_windowed_mul.rs:131-173, gadgets/curve.rs:245-285, gadgets/ecdsa.rs:55-78) on CURVE_SECP256K1 or
+    CURVE_P256.  ``blind`` = the point the gadget draws with rand() while the circuit is built, as (x, y) ints."""
+
+    def __init__(self, ctx, kind: int, curve: int, blind):
+        self._ctx, self.kind, self.curve = ctx, kind, curve
+        bx = np.frombuffer(int(blind[0]).to_bytes(32, "little"), np.uint8).copy()
+        by = np.frombuffer(int(blind[1]).to_bytes(32, "little"), np.uint8).copy()
+        h = C.c_void_p()
+        rc = ctx._L.p2e_curve_program_create(ctx._h, C.c_int(kind), C.c_int(curve), _ptr(bx), _ptr(by), C.byref(h))
+        if rc != 0:
+            raise P2EError(f"p2e_curve_program_create failed ({rc}): {ctx._L.p2e_last_error().decode()}")
+        self._h = h
+        self.num_cols = int(ctx._L.p2e_curve_program_num_cols(h))
+        self.num_aux_cols = int(ctx._L.p2e_curve_program_num_aux_cols(h))
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):
+            self._ctx._L.p2e_curve_program_destroy(self._ctx._h, self._h)
+        self._h = None
+
+    __del__ = close
+
+    def scratch_bytes(self, n):
+        return int(self._ctx._L.p2e_curve_program_scratch_bytes(self._h, C.c_size_t(n)))
+
+    def describe(self):
+        """(kind, field, first_col, num_cols, label) per generator, registration order (as schedule_describe)."""
+        L = self._ctx._L
+        n = L.p2e_curve_program_describe(self._h, None, C.c_size_t(0))
+        arr = (_GenDesc * n)()
+        L.p2e_curve_program_describe(self._h, arr, C.c_size_t(n))
+        kinds = ("add", "sub", "add_many", "mul", "inv", "glv")
+        return [(kinds[d.kind], d.field, d.first_col, d.num_cols, d.label.decode()) for d in arr]
+
+    def wiring(self):
+        """([(src, num_limbs), ...], range_check) per generator (as schedule_wiring); constants through const()."""
+        L = self._ctx._L
+        n = L.p2e_curve_program_wiring(self._h, None, C.c_size_t(0))
+        arr = (_GenWiring * n)()
+        L.p2e_curve_program_wiring(self._h, arr, C.c_size_t(n))
+        return [([(int(w.src[k]), int(w.num_limbs[k])) for k in range(w.num_operands)], bool(w.range_check)) for w in arr]
+
+    def aux_describe(self):
+        """(kind code, first_col, num_cols, label) of the built-in-generator targets the wiring refers to."""
+        L = self._ctx._L
+        n = L.p2e_curve_program_aux_describe(self._h, None, C.c_size_t(0))
+        arr = (_AuxDesc * n)()
+        L.p2e_curve_program_aux_describe(self._h, arr, C.c_size_t(n))
+        return [(int(d.kind), d.first_col, d.num_cols, d.label.decode()) for d in arr]
+
+    def const(self, const_id: int) -> int:
+        buf = (C.c_uint8 * 32)()
+        if self._ctx._L.p2e_curve_program_const(self._h, C.c_uint32(const_id), buf) != 0:
+            raise P2EError("unknown constant id")
+        return int.from_bytes(bytes(buf), "little")
+
+    def _out(self, n, cols, err, valid, ld):
+        ctx = self._ctx
+        if cols is None:
+            ld = n + 16 if (n >= 4096 and n & (n - 1) == 0) else n
+            full = ctx._cols(self.num_cols, ld)
+            cols = full[:, :n] if ld != n else full
+        err = err if err is not None else ctx._vec(n, np.uint8)
+        valid = valid if valid is not None else ctx._vec(n, np.uint8)
+        return cols, err, valid, ld if ld is not None else _ld(cols)
+
+    def mul_witness_batch(self, px, py, k, cols=None, err=None, valid=None, ld=None):
+        """(num_cols, n) columns of every generator the gadget registers for n (point, scalar) pairs."""
+        ctx = self._ctx
+        n = ctx._shape(px)[0]
+        cols, err, valid, ld = self._out(n, cols, err, valid, ld)
+        bad = ctx._check(ctx._L.p2e_curve_mul_witness_batch(ctx._h, self._h, _ptr(px), _ptr(py), _ptr(k), _ptr(cols), C.c_size_t(n),
+                                                            C.c_size_t(ld), _ptr(err), _ptr(valid)))
+        return cols, err, valid, bad
+
+    def verify_witness_batch(self, msg, r, s, pkx, pky, cols=None, err=None, valid=None, ld=None):
+        """verify_p256_message_circuit: (115557, n) columns."""
+        ctx = self._ctx
+        n = ctx._shape(msg)[0]
+        cols, err, valid, ld = self._out(n, cols, err, valid, ld)
+        bad = ctx._check(ctx._L.p2e_p256_verify_witness_batch(ctx._h, self._h, _ptr(msg), _ptr(r), _ptr(s), _ptr(pkx), _ptr(pky),
+                                                              _ptr(cols), C.c_size_t(n), C.c_size_t(ld), _ptr(err), _ptr(valid)))
+        return cols, err, valid, bad
 
 
 class _WireMap:

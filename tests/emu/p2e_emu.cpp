@@ -505,6 +505,19 @@ long emu_curve_program_gens(int kind, int curve, const uint8_t* blind_x, const u
     }
     return (long)g.size();
 }
+// value of constant `id` of a curve program (source code AUX_SRC_CONST | id); 0, or -1 for an unknown id
+int emu_curve_program_const(int kind, int curve, const uint8_t* blind_x, const uint8_t* blind_y, uint32_t id, uint8_t* out32) {
+    Aff blind;
+    memcpy(blind.x.w, blind_x, 32);
+    memcpy(blind.y.w, blind_y, 32);
+    host::CurveProgramHost H;
+    if (!host::make_curve_program(H, kind, curve, blind)) return -1;
+    id &= 0xFFFFu;
+    if (id >= 0x8000u ? id - 0x8000u >= H.sb.gvals.size() : (id >> 1) >= H.sb.gpts.size()) return -1;
+    const U256 v = H.sb.cval(id);
+    memcpy(out32, v.w, 32);
+    return 0;
+}
 int emu_synth_signatures_curve(int curve, uint64_t seed, size_t first, size_t n, uint8_t* msg32, uint8_t* r32, uint8_t* s32,
                                uint8_t* pkx32, uint8_t* pky32) {
 #pragma omp parallel for

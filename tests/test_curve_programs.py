@@ -1,0 +1,402 @@
+"""Curve programs: curve_scalar_mul_windowed (gadgets/curve_windowed_mul.rs:131-173),
+curve_scalar_mul (gadgets/curve.rs:245-285) on secp256k1 and P-256, verify_p256_message_circuit (gadgets/ecdsa.rs:55-78).
+
+CPU tests: the big-int gadget walk against the committed goldens, the goldens through the constraint replay, the
+kernel bodies (compiled for the CPU, tests/emu) against both, the schedule builder's operand wiring against the
+replay's.  GPU tests: the HIP kernels through the C ABI against the goldens, the emulation and the big-int walk, and
+their output through the constraint replay with no oracle value involved.
+
+"parity unpinned": the reference holds no vectors for these gadgets and cannot be built here."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import check_circuit as CC
+import p2e_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+META = json.load(open(os.path.join(GOLD, "curve_programs.json")))
+PROGRAMS = list(META)
+CURVES = [R.SECP256K1, R.P256]
+SRC_AUX, SRC_INPUT, SRC_CONST = 0x20000000, 0x40000000, 0x80000000
+
+
+def _npz():
+    return np.load(os.path.join(GOLD, "curve_programs.npz"))
+
+
+def _int(a):
+    return int.from_bytes(bytes(bytearray(a)), "little")
+
+
+def _case_ints(name):
+    z = _npz()
+    blind = (_int(z[name + "_blind"][0]), _int(z[name + "_blind"][1]))
+    ins = z[name + "_inputs"]
+    return blind, [[_int(ins[i, k]) for k in range(ins.shape[1])] for i in range(ins.shape[0])], z[name + "_cols0"]
+
+
+def _digest(v):
+    return hashlib.sha256(np.asarray(v, dtype="<u8").tobytes()).hexdigest()
+
+
+def _walk(name, blind, case):
+    kind, cv = META[name]["kind"], CURVES[META[name]["curve"]]
+    if kind == 1:
+        cols, aux, ops, _ = R.windowed_mul_witness(cv, *case, blind)
+        return cols, aux, ops, 1
+    if kind == 2:
+        cols, aux, ops, _ = R.scalar_mul_witness(cv, *case, blind)
+        return cols, aux, ops, 1
+    cols, aux, ok, ops = R.verify_p256_witness(*case, blind)
+    return cols, aux, ops, int(ok)
+
+
+def _replay(name, cols, blind, case, aux=None):
+    kind, cv = META[name]["kind"], CURVES[META[name]["curve"]]
+    if kind == 1:
+        return CC.check_windowed_mul(cv, cols, *case, blind, aux=aux)[0]
+    if kind == 2:
+        return CC.check_scalar_mul(cv, cols, *case, blind, aux=aux)[0]
+    return CC.check_verify_p256(cols, *case, blind, aux=aux)
+
+
+# ---- the kernel bodies compiled for the CPU (tests/emu) -----------------------------------------------------------
+class Emu:
+    def __init__(self):
+        self.L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libp2e_emu.so"))
+        self.L.emu_curve_program.restype = C.c_long
+        self.L.emu_curve_program_gens.restype = C.c_long
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+    def sizes(self, kind, curve, blind):
+        nc, ng, na = C.c_long(), C.c_long(), C.c_long()
+        rc = self.L.emu_curve_program(kind, curve, self._p(blind[0]), self._p(blind[1]), None, None, None, None, None, None,
+                                      C.c_size_t(0), C.c_size_t(0), None, None, 32, C.byref(nc), C.byref(ng), C.byref(na))
+        assert rc == 0
+        return nc.value, ng.value, na.value
+
+    def run(self, kind, curve, blind, args, piece=32):
+        """args: (px, py, k) or (msg, r, s, pkx, pky), each (n, 32) uint8"""
+        if len(args) == 3:
+            px, py, k = args
+            msg = r = s = k
+        else:
+            msg, r, s, px, py = args
+        n = px.shape[0]
+        nc, _, _ = self.sizes(kind, curve, blind)
+        cols, err, valid = np.zeros((nc, n), np.uint64), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        bad = self.L.emu_curve_program(kind, curve, self._p(blind[0]), self._p(blind[1]), self._p(msg), self._p(r), self._p(s),
+                                       self._p(px), self._p(py), self._p(cols), C.c_size_t(n), C.c_size_t(n), self._p(err),
+                                       self._p(valid), piece, None, None, None)
+        return cols, err, valid, bad
+
+    def gens(self, kind, curve, blind):
+        _, ng, _ = self.sizes(kind, curve, blind)
+        kinds, fields = np.zeros(ng, np.int32), np.zeros(ng, np.int32)
+        first, ncols = np.zeros(ng, np.uint32), np.zeros(ng, np.uint32)
+        src, nl = np.zeros((ng, 4), np.uint32), np.zeros((ng, 4), np.uint8)
+        assert self.L.emu_curve_program_gens(kind, curve, self._p(blind[0]), self._p(blind[1]), self._p(kinds), self._p(fields),
+                                             self._p(first), self._p(ncols), self._p(src), self._p(nl), C.c_size_t(ng)) == ng
+        return kinds, fields, first, ncols, src, nl
+
+    def const(self, kind, curve, blind, cid):
+        out = np.zeros(32, np.uint8)
+        assert self.L.emu_curve_program_const(kind, curve, self._p(blind[0]), self._p(blind[1]), C.c_uint32(cid), self._p(out)) == 0
+        return _int(out)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return Emu()
+
+
+def _golden_arrays(name):
+    z = _npz()
+    blind = (np.ascontiguousarray(z[name + "_blind"][0]), np.ascontiguousarray(z[name + "_blind"][1]))
+    ins = z[name + "_inputs"]
+    return blind, [np.ascontiguousarray(ins[:, k, :]) for k in range(ins.shape[1])]
+
+
+# ---- CPU ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_gadget_walk_reproduces_the_goldens(name):
+    blind, cases, cols0 = _case_ints(name)
+    m = META[name]
+    for i, case in enumerate(cases):
+        cols, aux, ops, ok = _walk(name, blind, case)
+        assert (len(cols), len(aux), len(ops)) == (m["num_cols"], m["num_aux"], m["num_gens"])
+        assert _digest(cols) == m["cases"][i]["cols_sha256"] and _digest(aux) == m["cases"][i]["aux_sha256"]
+        assert ok == m["cases"][i]["valid"]
+        if i == 0:
+            assert np.array_equal(np.asarray(cols, np.uint64), cols0)
+
+
+def test_native_results_of_the_gadgets():
+    """the gadgets compute k * P (curve/curve_multiplication.rs): the result limbs of the last curve_add"""
+    rng = R.SplitMix64(99)
+    for cv in CURVES:
+        blind = cv.mul(rng.below(cv.n), cv.g)
+        p = cv.mul(rng.below(cv.n), cv.g)
+        k = rng.below(cv.n)
+        assert R.windowed_mul_witness(cv, p[0], p[1], k, blind)[3] == cv.mul(k, p)
+        assert R.scalar_mul_witness(cv, p[0], p[1], k, blind)[3] == cv.mul(k, p)
+    # P-256: generator on the curve, order of the group (curve/p256.rs:67-81 test_generator_is_on_curve)
+    assert R.P256.on_curve(R.P256.g) and R.P256.mul(R.P256.n, R.P256.g) is None
+
+
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_goldens_pass_the_constraint_replay_and_mutations_do_not(name):
+    blind, cases, cols0 = _case_ints(name)
+    cols, aux, ops, ok = _walk(name, blind, cases[0])
+    c = _replay(name, cols0, blind, cases[0], aux=aux)
+    assert len(c.gens) == META[name]["num_gens"] and len(c.aux) == META[name]["num_aux"]
+    # one corrupted column in each generator kind: rejected
+    seen = {}
+    for kind, field, c0, nc, label, _ in c.gens:
+        seen.setdefault((kind, field), []).append((c0, nc))
+    for (kind, field), blocks in seen.items():
+        c0, nc = blocks[len(blocks) // 2]
+        for off in (0, nc - 1):
+            bad = cols0.copy()
+            bad[c0 + off] = int(bad[c0 + off]) ^ 1
+            with pytest.raises(CC.ConstraintViolation):
+                _replay(name, bad, blind, cases[0])
+    if META[name]["kind"] == 3:   # the tampered signature fails exactly its last connect
+        colsx, _, _, okx = _walk(name, blind, cases[-1])
+        assert okx == 0
+        with pytest.raises(CC.ConstraintViolation) as e:
+            _replay(name, colsx, blind, cases[-1])
+        assert "connect_nonnative(r, point.x)" in str(e.value)
+
+
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_kernel_bodies_match_the_goldens(name, emu):
+    m = META[name]
+    blind, args = _golden_arrays(name)
+    _, _, cols0 = _case_ints(name)
+    assert emu.sizes(m["kind"], m["curve"], blind) == (m["num_cols"], m["num_gens"], m["num_aux"])
+    cols, err, valid, bad = emu.run(m["kind"], m["curve"], blind, args)
+    assert bad == 0 and not err.any()
+    assert np.array_equal(cols[:, 0], cols0)
+    for i, cs in enumerate(m["cases"]):
+        assert _digest(cols[:, i]) == cs["cols_sha256"], (name, i)
+        assert int(valid[i]) == cs["valid"]
+    # the cut into pieces (inversion batches) must not change any output
+    cols2, _, valid2, _ = emu.run(m["kind"], m["curve"], blind, args, piece=7)
+    assert np.array_equal(cols, cols2) and np.array_equal(valid, valid2)
+
+
+def test_kernel_bodies_edge_inputs(emu):
+    """scalar 0 ends in result == -(2^264 starting point): the reference panics in inverse() (gadgets/nonnative.rs:863),
+    the kernels flag the element; scalars above the group order and a raw (non-canonical) point coordinate are
+    legal inputs of the gadgets and must agree with the walk (mul_nonnative reads raw limbs, quirk Q3)."""
+    rng = R.SplitMix64(5)
+    for ci, cv in enumerate(CURVES):
+        blind = cv.mul(rng.below(cv.n), cv.g)
+        b = (np.frombuffer(blind[0].to_bytes(32, "little"), np.uint8).copy(), np.frombuffer(blind[1].to_bytes(32, "little"), np.uint8).copy())
+        pts = [cv.mul(rng.below(cv.n), cv.g) for _ in range(3)]
+        ks = [0, cv.n + 5, (1 << 256) - 1]
+        xs = [pts[0][0], pts[1][0], pts[2][0]]
+        if pts[2][0] + cv.p < 1 << 256:
+            xs[2] = pts[2][0] + cv.p          # same field element, raw limbs differ
+        arr = lambda vs: np.stack([np.frombuffer(int(v).to_bytes(32, "little"), np.uint8).copy() for v in vs])
+        for kind, f in ((1, R.windowed_mul_witness), (2, R.scalar_mul_witness)):
+            cols, err, valid, bad = emu.run(kind, ci, b, (arr(xs), arr([p[1] for p in pts]), arr(ks)))
+            assert err[0] & R.ERR_INVERSE_OF_ZERO and bad == 1
+            with pytest.raises(R.RefPanic):
+                f(cv, xs[0], pts[0][1], ks[0], blind)
+            for i in (1, 2):
+                ref = f(cv, xs[i], pts[i][1], ks[i], blind)[0]
+                assert err[i] == 0 and np.array_equal(cols[:, i], np.asarray(ref, np.uint64)), (cv.name, kind, i)
+
+
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_builder_wiring_equals_the_replayed_gadget_wiring(name, emu):
+    """the C++ schedule builder's generator table and operand wiring (p2e_curve_program_describe / _wiring) against the
+    sources the constraint replay records while it walks the reference's gadgets"""
+    m = META[name]
+    blind_i, cases, cols0 = _case_ints(name)
+    blind, _ = _golden_arrays(name)
+    c = _replay(name, cols0, blind_i, cases[0])
+    kinds, fields, first, ncols, src, nl = emu.gens(m["kind"], m["curve"], blind)
+    names = ("add", "sub", "add_many", "mul", "inv", "glv")
+    slot = {"pky": 0, "py": 0, "pkx": 1, "px": 1, "msg": 2, "k": 2, "r": 3, "s": 4}
+    assert len(c.gens) == len(kinds)
+    consts = {}
+    for g, (kind, field, c0, nc, label, operands) in enumerate(c.gens):
+        assert (names[kinds[g]], int(fields[g]), int(first[g]), int(ncols[g])) == (kind, field, c0, nc), (g, label)
+        for k, limbs in enumerate(operands):
+            limbs, s, n_l = list(limbs), int(src[g, k]), int(nl[g, k])
+            assert len(limbs) == n_l, (label, kind, k)
+            if s & SRC_CONST:
+                cid = s & 0xFFFF
+                if cid not in consts:
+                    consts[cid] = emu.const(m["kind"], m["curve"], blind, cid)
+                want = R.const_limbs(consts[cid])
+                if n_l == len(want):
+                    assert [v for *_, v in limbs] == want or [x[0] for x in limbs] == ["virt"] * n_l
+                else:   # curve_scalar_mul's virtual `result` carries the constant in 9 limbs
+                    assert limbs[0][0] == "virt" and n_l == R.NL
+                continue
+            if n_l == 0:
+                continue
+            f0 = limbs[0]
+            if f0[0] == "col":
+                assert s == f0[1] and limbs == [("col", f0[1] + j) for j in range(n_l)]
+            elif f0[0] == "aux":
+                assert s == SRC_AUX | f0[1] and limbs == [("aux", f0[1] + j) for j in range(n_l)], (label, kind, k)
+            else:
+                assert f0[0] == "in" and s == SRC_INPUT | slot[f0[1]], (label, f0)
+
+
+def test_p256_field_arithmetic_against_bigints(emu):
+    """Barrett reduction with exact quotient (csrc/fe.hpp reduce_barrett) through the mul / inv generators of the
+    verifier's scalar phase: u1 = msg * s^-1, u2 = r * s^-1 (mod n) and their quotient limbs, on structured operands"""
+    cv = R.P256
+    rng = R.SplitMix64(77)
+    blind = cv.mul(rng.below(cv.n), cv.g)
+    b = (np.frombuffer(blind[0].to_bytes(32, "little"), np.uint8).copy(), np.frombuffer(blind[1].to_bytes(32, "little"), np.uint8).copy())
+    pk = cv.mul(rng.below(cv.n), cv.g)
+    vals = [1, 2, cv.n - 1, cv.n - 2, (1 << 255), (1 << 256) - 1, cv.n + 1, 0xFFFFFFFF00000000FFFFFFFF, rng.below(cv.n)]
+    arr = lambda vs: np.stack([np.frombuffer(int(v).to_bytes(32, "little"), np.uint8).copy() for v in vs])
+    n = len(vals)
+    msg, r, s = arr(vals), arr(vals[::-1]), arr([vals[(i * 5 + 2) % n] for i in range(n)])
+    cols, err, valid, bad = emu.run(3, 1, b, (msg, r, s, arr([pk[0]] * n), arr([pk[1]] * n)))
+    for i in range(n):
+        try:
+            ref = R.verify_p256_witness(_int(msg[i]), _int(r[i]), _int(s[i]), pk[0], pk[1], blind)[0]
+        except R.RefPanic:
+            assert err[i] != 0
+            continue
+        assert np.array_equal(cols[:, i], np.asarray(ref, np.uint64)), i
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    assert torch.cuda.is_available(), "the -m gpu tests need the MI355X"
+    return p2e, torch, p2e.Context(device=0)
+
+
+def _gpu_run(gpu, name_or_kind, curve, blind_i, args):
+    p2e, torch, ctx = gpu
+    prog = p2e.CurveProgram(ctx, name_or_kind, curve, blind_i)
+    dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in args]
+    if len(args) == 3:
+        cols, err, valid, bad = prog.mul_witness_batch(*dev)
+    else:
+        cols, err, valid, bad = prog.verify_witness_batch(*dev)
+    torch.cuda.synchronize()
+    out = cols.cpu().numpy().view(np.uint64), err.cpu().numpy(), valid.cpu().numpy(), bad
+    return prog, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_gpu_matches_the_goldens(name, gpu):
+    m = META[name]
+    blind_i, cases, cols0 = _case_ints(name)
+    _, args = _golden_arrays(name)
+    prog, (cols, err, valid, bad) = _gpu_run(gpu, m["kind"], m["curve"], blind_i, args)
+    assert prog.num_cols == m["num_cols"] and prog.num_aux_cols == m["num_aux"] and bad == 0
+    assert np.array_equal(cols[:, 0], cols0)
+    for i, cs in enumerate(m["cases"]):
+        assert _digest(cols[:, i]) == cs["cols_sha256"] and int(valid[i]) == cs["valid"]
+    # the output of the HIP kernels through the constraint replay: no oracle value involved
+    _replay(name, cols[:, 1], blind_i, cases[1])
+    prog.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_gpu_ragged_batch_against_the_emulation_and_the_walk(name, gpu, emu):
+    """300 random inputs (one full workgroup of paired stores + a ragged tail): every column against the kernel bodies
+    compiled for the CPU, three signatures against the big-int walk"""
+    p2e, torch, ctx = gpu
+    m = META[name]
+    cv = CURVES[m["curve"]]
+    rng = R.SplitMix64(1234 + m["kind"] + 10 * m["curve"])
+    blind_i = cv.mul(rng.below(cv.n), cv.g)
+    blind = (np.frombuffer(blind_i[0].to_bytes(32, "little"), np.uint8).copy(), np.frombuffer(blind_i[1].to_bytes(32, "little"), np.uint8).copy())
+    n = 300
+    sig = p2e.synth_signatures_curve(m["curve"], seed=42 + m["kind"], n=n)
+    if m["kind"] == 3:
+        args = sig
+        sig[0][7, 3] ^= 0x10            # one tampered message
+    else:
+        args = (sig[3], sig[4], sig[0])   # the public keys as points, the messages as scalars
+    prog, (cols, err, valid, bad) = _gpu_run(gpu, m["kind"], m["curve"], blind_i, args)
+    ecols, eerr, evalid, ebad = emu.run(m["kind"], m["curve"], blind, args)
+    assert bad == ebad == 0 and np.array_equal(err, eerr) and np.array_equal(valid, evalid)
+    assert np.array_equal(cols, ecols)
+    if m["kind"] == 3:
+        assert valid.sum() == n - 1 and valid[7] == 0
+    for i in (0, 7, n - 1):
+        ref = _walk(name, blind_i, [_int(a[i]) for a in args])[0]
+        assert np.array_equal(cols[:, i], np.asarray(ref, np.uint64))
+    # the library's tables against the emulation's (same builder, but through the C ABI)
+    kinds, fields, first, ncols, src, nl = emu.gens(m["kind"], m["curve"], blind)
+    names = ("add", "sub", "add_many", "mul", "inv", "glv")
+    desc, wiring = prog.describe(), prog.wiring()
+    assert len(desc) == len(kinds) == m["num_gens"]
+    for g in (0, 1, len(desc) // 2, len(desc) - 1):
+        assert desc[g][:4] == (names[kinds[g]], int(fields[g]), int(first[g]), int(ncols[g]))
+        assert wiring[g][0] == [(int(src[g, k]), int(nl[g, k])) for k in range(len(wiring[g][0]))]
+    assert prog.const(0) == blind_i[0] or m["kind"] == 3
+    assert sum(d[2] for d in prog.aux_describe()) == m["num_aux"]
+    prog.close()
+
+
+@pytest.mark.gpu
+def test_gpu_p256_verify_batch_properties(gpu):
+    """4 096 + 77 P-256 verifies: every valid signature verifies, every limb column is a 29-bit limb, tampering with
+    any of the five inputs clears `valid`, sampled signatures pass the constraint replay"""
+    p2e, torch, ctx = gpu
+    cv = R.P256
+    blind_i = cv.mul(0xC0FFEE, cv.g)
+    n = 4096 + 77
+    sig = p2e.synth_signatures_curve(p2e.CURVE_P256, seed=9, n=n)
+    for k in range(5):
+        sig[k][100 + k, 1] ^= 1
+    prog, (cols, err, valid, bad) = _gpu_run(gpu, p2e.CP_VERIFY, p2e.CURVE_P256, blind_i, sig)
+    assert bad == 0 and not err.any()
+    expect = np.ones(n, np.uint8)
+    expect[100:105] = 0
+    assert np.array_equal(valid, expect)
+    desc = prog.describe()
+    for kind, field, c0, nc, label in desc[:: max(1, len(desc) // 97)]:
+        limbs = 9 if kind in ("add", "sub", "add_many") else 18
+        assert int(cols[c0:c0 + limbs].max()) < 1 << 29, (kind, label)
+    for i in (0, n - 1):
+        CC.check_verify_p256(cols[:, i], *[_int(a[i]) for a in sig], blind_i)
+    prog.close()
+
+
+@pytest.mark.gpu
+def test_gpu_curve_program_misuse(gpu):
+    p2e, torch, ctx = gpu
+    with pytest.raises(p2e.P2EError):
+        p2e.CurveProgram(ctx, p2e.CP_VERIFY, p2e.CURVE_SECP256K1, R.SECP256K1.g)       # the verifier program is P-256 only
+    with pytest.raises(p2e.P2EError):
+        p2e.CurveProgram(ctx, 9, p2e.CURVE_P256, R.P256.g)
+    with pytest.raises(p2e.P2EError):
+        p2e.CurveProgram(ctx, p2e.CP_WINDOWED_MUL, p2e.CURVE_P256, ((1 << 256) - 1, 5))   # not a canonical field element
+    prog = p2e.CurveProgram(ctx, p2e.CP_WINDOWED_MUL, p2e.CURVE_P256, R.P256.g)
+    sig = [torch.from_numpy(a).cuda() for a in p2e.synth_signatures_curve(p2e.CURVE_P256, seed=1, n=8)]
+    with pytest.raises(p2e.P2EError):
+        prog.verify_witness_batch(*sig)                                                 # a multiplication program
+    cols, err, valid, bad = prog.mul_witness_batch(sig[3], sig[4], sig[0])              # a valid call still works
+    torch.cuda.synchronize()
+    assert bad == 0
+    prog.close()
