@@ -1,0 +1,67 @@
+"""Curve programs: fills/s and the roofline of their expansion kernel.
+One JSON line per (program, curve, batch): whole call (wall, median of REPS) and the expansion launches alone
+(kc_expand: algorithmic bytes = columns x 8 B x n, durations = the library's own HIP event pairs around every launch,
+p2e_last_phase_ms).  Usage: python tools/bench_curve_programs.py [log2 n ...]   (default 13 15)"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import plonky2_ecdsa_amd as p2e
+
+PEAK = 8000.0
+reps = int(os.environ.get("REPS", "5"))
+logs = [int(a) for a in sys.argv[1:]] or [13, 15]
+ctx = p2e.Context(device=0)
+# any point of the curve serves as the circuit's rand() point: 0xC0FFEE * G, computed by the synthetic-signature helper's
+# own arithmetic is not exposed, so take a public key of the synthetic stream (a uniformly random multiple of G)
+for curve, cname in ((p2e.CURVE_SECP256K1, "secp256k1"), (p2e.CURVE_P256, "p256")):
+    bsig = p2e.synth_signatures_curve(curve, seed=777, n=1)
+    blind = (int.from_bytes(bytes(bsig[3][0]), "little"), int.from_bytes(bytes(bsig[4][0]), "little"))
+    for kind, kname in ((p2e.CP_WINDOWED_MUL, "curve_scalar_mul_windowed"), (p2e.CP_SCALAR_MUL, "curve_scalar_mul"),
+                        (p2e.CP_VERIFY, "verify_p256_message_circuit")):
+        if kind == p2e.CP_VERIFY and curve != p2e.CURVE_P256:
+            continue
+        prog = p2e.CurveProgram(ctx, kind, curve, blind)
+        for lg in logs:
+            n = 1 << lg
+            sig = [torch.from_numpy(a).cuda() for a in p2e.synth_signatures_curve(curve, seed=5, n=n)]
+            ld = n + 16
+            cols = torch.empty((prog.num_cols, ld), dtype=torch.int64, device="cuda")
+            err = torch.empty(n, dtype=torch.uint8, device="cuda")
+            valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+            if kind == p2e.CP_VERIFY:
+                call = lambda: prog.verify_witness_batch(*sig, cols=cols[:, :n], err=err, valid=valid, ld=ld)
+            else:
+                call = lambda: prog.mul_witness_batch(sig[3], sig[4], sig[0], cols=cols[:, :n], err=err, valid=valid, ld=ld)
+            _, _, _, bad = call()
+            torch.cuda.synchronize()
+            ok = int(valid.sum().item())
+            ts, ph = [], []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                call()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t) * 1e3)
+                ph.append(ctx.last_phase_ms())
+            ts.sort()
+            ms = ts[len(ts) // 2]
+            exp_ms = sorted(p["expand"] for p in ph)[len(ph) // 2]
+            p0 = ph[0]
+            alg = p0["expand_cols"] * 8 * n
+            out_bytes = prog.num_cols * 8 * n
+            print(json.dumps({"program": kname, "curve": cname, "n": n, "cols_per_fill": prog.num_cols, "flagged": bad, "valid": ok,
+                              "ms": round(ms, 3), "fills_per_s": round(n / ms * 1e3, 1),
+                              "whole_fill_GBps": round(out_bytes / ms / 1e6, 1), "whole_fill_frac_hbm_peak": round(out_bytes / ms / 1e6 / PEAK, 4),
+                              "roofline": {"kernel": "kc_expand", "bound": "hbm", "launches": int(p0["expand_launches"]),
+                                           "algorithmic_bytes": int(alg), "sum_launch_ms": round(exp_ms, 3),
+                                           "achieved": round(alg / exp_ms / 1e6, 1), "peak": PEAK, "unit": "GB/s",
+                                           "frac": round(alg / exp_ms / 1e6 / PEAK, 4)},
+                              "scalar_ms": round(p0["scalar"], 3), "scratch_GB": round(prog.scratch_bytes(n) / 1e9, 2)}), flush=True)
+            del cols, sig
+        prog.close()
