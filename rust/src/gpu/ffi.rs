@@ -63,6 +63,17 @@ pub const P2E_WIRE_SRC_GATE: u32 = 0xC000_0000;
 pub const P2E_COMPACT_WIDE: u32 = 0x8000_0000;
 
 #[link(name = "p2e_hip")]
+/// one built circuit of a curve program (include/p2e.h p2e_curve_program)
+#[repr(C)]
+pub struct P2eCurveProgram {
+    _private: [u8; 0],
+}
+pub const P2E_CURVE_SECP256K1: i32 = 0;
+pub const P2E_CURVE_P256: i32 = 1;
+pub const P2E_CP_WINDOWED_MUL: i32 = 1;
+pub const P2E_CP_SCALAR_MUL: i32 = 2;
+pub const P2E_CP_VERIFY: i32 = 3;
+
 extern "C" {
     // ---- context
     pub fn p2e_ctx_create(device: i32, flags: u32, stream: *mut c_void, out: *mut *mut P2eCtx) -> i32;
@@ -134,4 +145,21 @@ extern "C" {
         row_ld: usize) -> i64;
     pub fn p2e_columns_compact(ctx: *mut P2eCtx, program: i32, cols: *const u64, ld: usize, n: usize, narrow: *mut u32,
         ld_narrow: usize, wide: *mut u64, ld_wide: usize, err: *mut u8) -> i64;
+
+    // ---- curve programs (rank 4): curve_scalar_mul_windowed / curve_scalar_mul on either curve, verify_p256_message_circuit
+    pub fn p2e_curve_program_create(ctx: *mut P2eCtx, kind: i32, curve: i32, blind_x32: *const u8, blind_y32: *const u8,
+        out: *mut *mut P2eCurveProgram) -> i32;
+    pub fn p2e_curve_program_destroy(ctx: *mut P2eCtx, prog: *mut P2eCurveProgram);
+    pub fn p2e_curve_program_num_cols(prog: *const P2eCurveProgram) -> i64;
+    pub fn p2e_curve_program_num_aux_cols(prog: *const P2eCurveProgram) -> i64;
+    pub fn p2e_curve_program_scratch_bytes(prog: *const P2eCurveProgram, n: usize) -> usize;
+    pub fn p2e_curve_program_describe(prog: *const P2eCurveProgram, out: *mut P2eGenDesc, cap: usize) -> i64;
+    pub fn p2e_curve_program_wiring(prog: *const P2eCurveProgram, out: *mut P2eGenWiring, cap: usize) -> i64;
+    pub fn p2e_curve_program_aux_describe(prog: *const P2eCurveProgram, out: *mut P2eAuxDesc, cap: usize) -> i64;
+    pub fn p2e_curve_program_const(prog: *const P2eCurveProgram, id: u32, out32: *mut u8) -> i32;
+    pub fn p2e_curve_mul_witness_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, px32: *const u8, py32: *const u8,
+        k32: *const u8, cols: *mut u64, n: usize, ld: usize, err: *mut u8, valid: *mut u8) -> i64;
+    pub fn p2e_p256_verify_witness_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, msg32: *const u8, r32: *const u8,
+        s32: *const u8, pkx32: *const u8, pky32: *const u8, cols: *mut u64, n: usize, ld: usize, err: *mut u8,
+        valid: *mut u8) -> i64;
 }
