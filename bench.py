@@ -22,8 +22,10 @@ Extra objects on the line:
                per launch / average launch duration, the duration measured live with HIP events on the
                stream the kernel runs on (p2e_last_phase_ms).  traffic = HBM bytes per launch from the
                rocprofv3 PMC summary committed under profiles/ (null if absent).
-  roofline_k_expand   the same figures for k_expand (window table, fixed-base chain, trailing adds: 22 572
-               columns, one curve op per workgroup row).
+  roofline_k_expand   the same figures for k_expand (window table and the three trailing adds: 6 006 columns, one
+               curve op per workgroup row).
+  roofline_k_expand_fb_run   the same for k_expand_fb_run (the 66 fixed-base windows walked as one run per signature:
+               16 566 columns, one launch per step).
   roofline_limb_split   the 29-bit limb-split kernel (k_split, p2e_limb_split) on 2^26 packed 256-bit values:
                104 algorithmic bytes per element (32 in + 72 out), torch events on the stream it runs on.
   cpu_baseline oracle/libp2e_oracle.so (C restatement of the reference's CPU algorithm: affine ops, one
@@ -224,14 +226,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kstat = {k: {"ms": [], "cols": 0.0, "launches": 0} for k in ("expand", "runs")}
+    kstat = {k: {"ms": [], "cols": 0.0, "launches": 0} for k in ("expand", "runs", "fbrun")}
     phase_acc = {}
 
     def note(ph, weight=1.0):
         for k, st in kstat.items():
             st["ms"].append(ph[k])
             st["cols"], st["launches"] = ph[k + "_cols"], int(ph[k + "_launches"])
-        for k in ("scalar", "expand", "runs", "total"):
+        for k in ("scalar", "expand", "runs", "fbrun", "total"):
             phase_acc[k] = phase_acc.get(k, 0.0) + ph[k] * weight
     step_s = []
     barrier()
@@ -353,9 +355,10 @@ def main():
                     "traffic_source": pmc.get("source")}
 
         runs_line, expand_line = roofline("k_expand_runs", kstat["runs"]), roofline("k_expand", kstat["expand"])
+        fbrun_line = roofline("k_expand_fb_run", kstat["fbrun"])
         bytes_per_fill = BYTES_PER_FILL
         if args.compact:   # the per-kernel byte counts above assume 8-byte columns: not quoted for this container
-            runs_line = expand_line = None
+            runs_line = expand_line = fbrun_line = None
             bytes_per_fill = 160 + NN * 4 + NW * 8
         line = {
             "metric": "secp256k1 ECDSA witness fills/sec at batch=2^16, 1/2/4/8 MI355X; bit-exact",
@@ -381,6 +384,8 @@ def main():
         }
         if runs_line:
             line["roofline_k_expand"] = expand_line
+        if fbrun_line:
+            line["roofline_k_expand_fb_run"] = fbrun_line
         if step_s:
             med = sorted(step_s)[len(step_s) // 2]
             line["median_step_ms"] = round(med * 1e3, 4)            # median of the timed steps

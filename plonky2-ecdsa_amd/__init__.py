@@ -413,11 +413,12 @@ class Context:
         return self._check(self._L.p2e_sync(self._h))
 
     def last_phase_ms(self):
-        """include/p2e.h p2e_last_phase_ms: `expand*` = k_expand launches, `runs*` = k_expand_runs launches."""
-        buf = (C.c_float * 8)()
-        self._L.p2e_last_phase_ms(self._h, buf, C.c_int(8))
+        """include/p2e.h p2e_last_phase_ms: `expand*` = k_expand launches, `runs*` = k_expand_runs launches, `fbrun*` =
+        k_expand_fb_run launches (per kind: launches, columns written per signature, summed HIP-event durations in ms)."""
+        buf = (C.c_float * 12)()
+        self._L.p2e_last_phase_ms(self._h, buf, C.c_int(12))
         return dict(zip(("scalar", "expand_launches", "expand_cols", "expand", "total", "runs_launches", "runs_cols",
-                         "runs"), [float(x) for x in buf]))
+                         "runs", "fbrun_launches", "fbrun_cols", "fbrun"), [float(x) for x in buf]))
 
     # ---- allocation helpers -------------------------------------------------------------------------
     def _cols(self, k, n):

@@ -124,6 +124,12 @@ __global__ __launch_bounds__(BS) void k_expand_runs(Program G, Buffers B, int it
     int it1 = it0 + run_iters < it_end ? it0 + run_iters : it_end;
     if ((MODE & 1) || i < B.n) body_expand_run<typename EmitOf<MODE>::type>(G, B, i, it0, it1);
 }
+// all fixed-base windows of a signature as one run (body_expand_fb_run); t_after: the unblinding add
+template <int MODE>
+__global__ __launch_bounds__(BS) void k_expand_fb_run(Program G, Buffers B, int t_after, size_t first) {
+    size_t i = lane_sig<(MODE & 1) != 0>(first);
+    if ((MODE & 1) || i < B.n) body_expand_fb_run<typename EmitOf<MODE>::type>(G, B, i, t_after);
+}
 // p2e_ecdsa_verify_batch: the connect r == x of gadgets/ecdsa.rs:48-52 on the final add's Jacobian result, without an
 // inversion: x = X / Z^2 is canonical, so x == r  <=>  r < p and X == r * Z^2 (Z != 0, else phase A flagged the element)
 __global__ __launch_bounds__(BS) void k_verify_check(Program G, Buffers B) {
@@ -492,7 +498,7 @@ struct p2e_ctx {
     hipStream_t st_msm = nullptr, st_fixed = nullptr, st_binv = nullptr, st_c2 = nullptr;
     hipEvent_t ev_c2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_fixed = nullptr, ev_piece[MAX_SEG] = {}, ev_binv[MAX_SEG] = {};
-    // one event pair around every expansion launch; kind 0 = k_expand (op by op), 1 = k_expand_runs
+    // one event pair around every expansion launch; kind 0 = k_expand (op by op), 1 = k_expand_runs, 2 = k_expand_fb_run
     static constexpr int MAX_EXPAND = 2 * MAX_SEG;
     hipEvent_t ev_c0[MAX_EXPAND] = {}, ev_c1[MAX_EXPAND] = {};
     int n_expand = 0, n_seg = 0;
@@ -501,6 +507,7 @@ struct p2e_ctx {
     int msm_pieces = 8, fixed_pieces = 2;   // one Montgomery inversion batch per piece
     int msm_pieces_small = 5, fixed_pieces_small = 1;   // ... of the small-batch plan (fewer launches and inversions)
     int run_iters = 9;                      // MSM-loop iterations per expansion run (0: expand op by op)
+    bool fb_run = true;                     // with runs: the fixed-base windows as one run per signature (k_expand_fb_run)
     // A run is walked by ONE lane, so a launch of r runs has only r * n/64 waves: below this batch size the
     // 1024 SIMDs are better filled by one workgroup row per op (2^10 glv_mul fills: 3.0 ms against 9.5 ms)
     size_t runs_min_n = 49152;
@@ -526,7 +533,8 @@ struct p2e_ctx {
     unsigned long long* d_counter = nullptr;
     unsigned long long* h_counter = nullptr;  // pinned
     hipEvent_t ev[6] = {};   // [0],[1] around k_scalar, [5] end of the call (2..4 unused)
-    float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float phase_ms[12] = {0};   // [0] scalar, [4] whole call, per expansion kind k (launches, columns, summed ms): [1..3] k_expand,
+                                // [5..7] k_expand_runs, [8..10] k_expand_fb_run
     bool have_phases = false;
 };
 
@@ -578,13 +586,13 @@ static const DeviceProgram& host_program(int program) {
     });
     return P[program];
 }
-static std::vector<OpDesc> host_ops(int program, int run_iters) {
+static std::vector<OpDesc> host_ops(int program, int run_iters, bool fb_run = true) {
     host::ScheduleBuilder b;
     if (program == 0)
         b.verify_secp256k1_message_circuit();
     else
         b.glv_mul_circuit();
-    b.mark_runs(run_iters);
+    b.mark_runs(run_iters, fb_run);
     return b.ops;
 }
 
@@ -671,6 +679,7 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         int v = atoi(env);
         if (v >= 0 && v <= MSM_DIGITS) c->run_iters = v;
     }
+    if (getenv("P2E_NO_FB_RUN")) c->fb_run = false;
     if (const char* env = getenv("P2E_RUNS_MIN_N")) c->runs_min_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_QUAD_MAX_N")) c->quad_max_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_EXPAND_LDS_SMALL")) c->expand_lds_small = (unsigned)strtoul(env, nullptr, 10);
@@ -701,7 +710,7 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     }
     for (int p = 0; p < 2; p++) {
         c->progs[p].prog = host_program(p).prog;
-        std::vector<OpDesc> ops = host_ops(p, c->run_iters);
+        std::vector<OpDesc> ops = host_ops(p, c->run_iters, c->fb_run);
         c->progs[p].h_ops = ops;
         HIP_TRY(hipMalloc(&c->progs[p].d_ops, sizeof(OpDesc) * ops.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_ops, ops.data(), sizeof(OpDesc) * ops.size(), hipMemcpyHostToDevice));
@@ -819,7 +828,8 @@ static std::string pipeline_progress(p2e_ctx* c) {
     }
     for (int k = 0; k < c->n_expand; k++)
         if (hipEventQuery(c->ev_c1[k]) != hipSuccess)
-            return std::string("phase C (") + (c->expand_kind[k] ? "k_expand_runs" : "k_expand") + "), launch " + std::to_string(k);
+            return std::string("phase C (") + (c->expand_kind[k] == 1 ? "k_expand_runs" : c->expand_kind[k] == 2 ? "k_expand_fb_run" : "k_expand") +
+                   "), launch " + std::to_string(k);
     return "finalisation";
 }
 
@@ -836,7 +846,7 @@ extern "C" int p2e_sync(p2e_ctx* c) {
     if (c->have_phases) {
         HIP_TRY(hipEventElapsedTime(&c->phase_ms[0], c->ev[0], c->ev[1]));   // scalar kernel
         HIP_TRY(hipEventElapsedTime(&c->phase_ms[4], c->ev[0], c->ev[5]));   // whole call
-        double cnt[2] = {0, 0}, cols[2] = {0, 0}, sum_ms[2] = {0, 0};
+        double cnt[3] = {0, 0, 0}, cols[3] = {0, 0, 0}, sum_ms[3] = {0, 0, 0};
         for (int k = 0; k < c->n_expand; k++) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev_c0[k], c->ev_c1[k]));
@@ -845,8 +855,8 @@ extern "C" int p2e_sync(p2e_ctx* c) {
             cols[kind] += c->expand_cols[k];
             sum_ms[kind] += ms;
         }
-        for (int kind = 0; kind < 2; kind++) {       // [1..3] k_expand, [5..7] k_expand_runs
-            const int o = kind == 0 ? 1 : 5;
+        for (int kind = 0; kind < 3; kind++) {       // [1..3] k_expand, [5..7] k_expand_runs, [8..10] k_expand_fb_run
+            const int o = kind == 0 ? 1 : kind == 1 ? 5 : 8;
             c->phase_ms[o] = (float)cnt[kind];       // launches
             c->phase_ms[o + 1] = (float)cols[kind];  // columns they wrote (per signature)
             c->phase_ms[o + 2] = (float)sum_ms[kind];  // their summed durations
@@ -857,7 +867,7 @@ extern "C" int p2e_sync(p2e_ctx* c) {
 
 extern "C" int p2e_last_phase_ms(p2e_ctx* c, float* out, int cap) {
     if (!c || !out) return P2E_E_INVALID;
-    int k = cap < 8 ? cap : 8;
+    int k = cap < 12 ? cap : 12;
     for (int i = 0; i < k; i++) out[i] = c->phase_ms[i];
     return k;
 }
@@ -1257,6 +1267,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         bool final_after;    // append the final add (needs the fixed-base chain) to this piece
         int s_lo, s_hi;      // ops expanded one by one (k_expand)
         int it0, it1;        // MSM-loop iterations expanded as runs (k_expand_runs)
+        bool fb_run;         // the fixed-base windows of this piece expanded as one run per signature (k_expand_fb_run)
     };
     Seg segs[p2e_ctx::MAX_SEG];
     int ns = 0;
@@ -1264,18 +1275,25 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     // small batches: four lanes per signature in phase A, split inversion batches in phase B (quad.hpp)
     const bool quad = n <= c->quad_max_n;
     const int msm_pieces = quad ? c->msm_pieces_small : c->msm_pieces;
-    const int fixed_pieces = quad ? c->fixed_pieces_small : c->fixed_pieces;
+    // with run expansion the fixed-base chain is ONE piece: its windows keep no X, Y / affine form in memory
+    // (F_NO_AFFINE), so nothing could resume the chain from scratch in the middle
+    const bool fb_run = run_iters > 0 && verify && c->fb_run && G.fb_begin == G.chain_begin[1];
+    const int fixed_pieces = fb_run ? 1 : quad ? c->fixed_pieces_small : c->fixed_pieces;
     auto cut = [&](int lo, int hi, int pieces, hipStream_t st) {
         if (pieces > hi - lo) pieces = hi - lo;
         int a = lo;
         for (int k = 0; k < pieces; k++) {
             int rem = pieces - k;
             int len = (hi - a + rem - 1) / rem;
-            segs[ns++] = Seg{a, a + len, a + len - lo, st, false, a, a + len, 0, 0};
+            segs[ns++] = Seg{a, a + len, a + len - lo, st, false, a, a + len, 0, 0, false};
             a += len;
         }
     };
     if (verify) cut(G.chain_begin[1], G.chain_end[1], fixed_pieces, c->st_fixed);
+    if (fb_run) {   // windows as one run, then the unblinding add op by op
+        segs[0].fb_run = true;
+        segs[0].s_lo = G.fb_begin + G.fb_windows;
+    }
     const int first_msm = ns;
     {
         // MSM chain = window table (its own piece: inverted first, read in affine form by everything after) +
@@ -1293,14 +1311,14 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             while (listed < p2e_ctx::MAX_PIECES - 1 && c->small_takes[listed] > 0 && sum + c->small_takes[listed] < nruns) sum += c->small_takes[listed++];
             groups = listed + 1;
         }
-        segs[ns++] = Seg{lo0, lb, lb - lo0, c->st_msm, false, lo0, lb, 0, 0};
+        segs[ns++] = Seg{lo0, lb, lb - lo0, c->st_msm, false, lo0, lb, 0, 0, false};
         int run = 0;
         for (int g = 0; g < groups; g++) {
             int rem = groups - g;
             int take = (nruns - run + rem - 1) / rem;
             if (listed) take = g < listed ? c->small_takes[g] : nruns - run;
             int it0 = run * R, it1 = (run + take) * R < iters ? (run + take) * R : iters;
-            Seg sg{lb + 3 * it0, lb + 3 * it1, lb + 3 * it1 - lo0, c->st_msm, false, 0, 0, it0, it1};
+            Seg sg{lb + 3 * it0, lb + 3 * it1, lb + 3 * it1 - lo0, c->st_msm, false, 0, 0, it0, it1, false};
             if (run_iters == 0) {   // no run expansion: op by op
                 sg.s_lo = sg.lo;
                 sg.s_hi = sg.hi;
@@ -1431,6 +1449,15 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 1;
             c->expand_cols[e] = cols_of(G.msm_loop_begin + 3 * sg.it0, G.msm_loop_begin + 3 * sg.it1);
+        }
+        if (sg.fb_run) {
+            const int e = c->n_expand++;
+            HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
+            if (gx_wide) LAUNCH_EMIT(k_expand_fb_run, true, dim3(gx_wide), st_c, G, B, G.fb_begin + G.fb_windows, (size_t)0);
+            if (gx_tail) LAUNCH_EMIT(k_expand_fb_run, false, dim3(gx_tail), st_c, G, B, G.fb_begin + G.fb_windows, n_wide);
+            HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
+            c->expand_kind[e] = 2;
+            c->expand_cols[e] = cols_of(G.fb_begin, G.fb_begin + G.fb_windows);
         }
         if (sg.s_hi > sg.s_lo) {
             const int e = c->n_expand++;

@@ -99,6 +99,9 @@ struct Program {
     // curve programs (curves.hpp; zero for the two built-in programs): kind, digit rows of the per-signature table /
     // bit selects, the column and constant of the one curve_neg(constant) generator, ops of the per-signature table
     int32_t cp_kind, cp_rows, cp_neg_col, cp_neg_const, cp_table_ops;
+    // the fixed-base windows: fb_windows conditional adds starting at op fb_begin (-1: none), and the doublings per
+    // iteration of the loop at msm_loop_begin (2: curve_msm_circuit, 4: curve_scalar_mul_windowed)
+    int32_t fb_begin, fb_windows, loop_dbls;
 };
 
 struct Buffers {
@@ -535,32 +538,65 @@ P2E_HD void body_expand(const Program& G, const Buffers& B, size_t i, int t, con
 // with the running point in registers (the affine results are by-products of the witness arithmetic), so per
 // op it only reads v^-1 (32 B) and, per iteration, one table point.  Phase B therefore converts only the two
 // candidates for the running point at the END of each run (F_NO_AFFINE on the rest).
-template <class E>
+// DBLS: doublings per iteration -- 2 in curve_msm_circuit (gadgets/curve_msm.rs:66-67), 4 in curve_scalar_mul_windowed
+// (gadgets/curve_windowed_mul.rs:157)
+template <class E, class CV = Secp256k1, int DBLS = 2>
 P2E_HD void body_expand_run(const Program& G, const Buffers& B, size_t i, int it0, int it1) {
     uint8_t err = 0;
-    int t = G.msm_loop_begin + 3 * it0;
+    int t = G.msm_loop_begin + (DBLS + 1) * it0;
     Aff p = load_aff_src(B, i, B.src[(size_t)(2 * t) * B.n + i]);
-    for (int it = it0; it < it1; it++, t += 3) {
+    for (int it = it0; it < it1; it++, t += DBLS + 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-        for (int k = 0; k < 2; k++) {  // curve_repeated_double(result, 2)
+        for (int k = 0; k < DBLS; k++) {  // curve_repeated_double(result, DBLS)
             E e = E::at(B.sink, i, load_op(B.ops, t + k).col);
-            p = wit_curve_double(e, p, B.PW[(size_t)(t + k) * B.n + i], err);
+            p = wit_curve_double<E, CV>(e, p, B.PW[(size_t)(t + k) * B.n + i], err);
             e.flush();
         }
-        const int tc = t + 2;
+        const int tc = t + DBLS;
         const uint16_t s2 = B.src[(size_t)(2 * tc + 1) * B.n + i];
         Aff p2 = load_aff_src(B, i, (uint16_t)(s2 & (DYN_CONST_BIT | SRC_ID_MASK)));
         const bool b = (s2 & SRC_SEL_BIT) != 0;
         E e = E::at(B.sink, i, load_op(B.ops, tc).col);
-        Aff sm = wit_curve_add(e, p, p2, B.PW[(size_t)tc * B.n + i], err);
+        Aff sm = wit_curve_add<E, CV>(e, p, p2, B.PW[(size_t)tc * B.n + i], err);
         const U256 z = u256_zero();
         Aff nx;
-        nx.x = wit_add<ModP>(e, u256_select(b, sm.x, z), u256_select(b, z, p.x));
-        nx.y = wit_add<ModP>(e, u256_select(b, sm.y, z), u256_select(b, z, p.y));
+        nx.x = wit_add<typename CV::Fp>(e, u256_select(b, sm.x, z), u256_select(b, z, p.x));
+        nx.y = wit_add<typename CV::Fp>(e, u256_select(b, sm.y, z), u256_select(b, z, p.y));
         e.flush();
         p = nx;
+    }
+    if (err) err_or(&B.err[i], err);
+}
+
+// Phase C over ALL fixed-base windows of one signature (gadgets/curve_fixed_base.rs:43-62): the lane walks the
+// conditional adds against the constant table with the running point in registers, so per op it reads only v^-1 and the
+// resolved table index; phase B then converts none of these results (F_NO_AFFINE) and phase A stores no X, Y for them.
+// The running point after the last window is the first operand of op t_after (the unblinding add): it is left in the
+// affine slot phase A resolved for that operand.
+template <class E, class CV = Secp256k1>
+P2E_HD void body_expand_fb_run(const Program& G, const Buffers& B, size_t i, int t_after) {
+    uint8_t err = 0;
+    int t = G.fb_begin;
+    Aff p = load_aff_src(B, i, B.src[(size_t)(2 * t) * B.n + i]);
+    for (int w = 0; w < G.fb_windows; w++, t++) {
+        const uint16_t s2 = B.src[(size_t)(2 * t + 1) * B.n + i];
+        const Aff p2 = B.fbtab[s2 & SRC_ID_MASK];
+        const bool b = (s2 & SRC_SEL_BIT) != 0;
+        E e = E::at(B.sink, i, load_op(B.ops, t).col);
+        Aff sm = wit_curve_add<E, CV>(e, p, p2, B.PW[(size_t)t * B.n + i], err);
+        const U256 z = u256_zero();
+        Aff nx;
+        nx.x = wit_add<typename CV::Fp>(e, u256_select(b, sm.x, z), u256_select(b, z, p.x));
+        nx.y = wit_add<typename CV::Fp>(e, u256_select(b, sm.y, z), u256_select(b, z, p.y));
+        e.flush();
+        p = nx;
+    }
+    const uint16_t dst = B.src[(size_t)(2 * t_after) * B.n + i];
+    if (!(dst & DYN_CONST_BIT)) {   // (every digit zero: the running point is still the constant it started from)
+        B.AX[(size_t)dst * B.n + i] = p.x;
+        B.AY[(size_t)dst * B.n + i] = p.y;
     }
     if (err) err_or(&B.err[i], err);
 }

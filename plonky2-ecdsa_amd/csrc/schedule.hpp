@@ -78,6 +78,7 @@ public:
     std::vector<GenOp> gens;
     std::vector<OpDesc> ops;
     Program prog{};
+    ScheduleBuilder() { prog.fb_begin = -1; }
     // constraint-block columns (ux.hpp): one item per generator with a non-empty block, and per
     // generator (same index as gens) its first ux column / column count
     std::vector<UxItem> ux_items;
@@ -183,6 +184,8 @@ public:
     AffinePointTarget fixed_base_curve_mul_circuit(NonNativeTarget scalar) {
         split_nonnative_to_4_bit_limbs(scalar);
         AffinePointTarget result = constant_affine_point(id_rando_);
+        prog.fb_begin = (int32_t)ops.size();
+        prog.fb_windows = FB_WINDOWS;
         for (int w = 0; w < FB_WINDOWS; w++) {
             Scope s(this, "win" + std::to_string(w));
             // is_equal(limb, zero), not, random_access_curve_points(limb, muls_point), curve_conditional_add
@@ -265,6 +268,9 @@ public:
         }
         for (int i = 0; i < 16; i++) prog.msm_tab[i] = pre[i].ref;
         prog.cp_rows = CP_WINDOWS;
+        loop_begin_ = (int32_t)ops.size();
+        loop_iters_ = CP_WINDOWS;
+        prog.loop_dbls = 4;
         for (int w = CP_WINDOWS - 1; w >= 0; w--) {
             Scope s(this, "window" + std::to_string(w));
             result = curve_repeated_double(result, 4, false);
@@ -382,6 +388,7 @@ public:
         AffinePointTarget result = rando;
         prog.msm_loop_begin = (int32_t)ops.size();
         prog.msm_loop_iters = MSM_DIGITS;
+        prog.loop_dbls = 2;
         for (int d = MSM_DIGITS - 1; d >= 0; d--) {
             Scope s(this, "digit" + std::to_string(d));
             result = curve_repeated_double(result, 2);
@@ -489,18 +496,23 @@ public:
 
     // Expansion runs of `run_iters` loop iterations: inside a run only the last (double, conditional add) pair
     // can be the next run's starting point, every other result never needs affine coordinates in memory.
-    void mark_runs(int run_iters) {
+    void mark_runs(int run_iters, bool mark_fb = true) {
         for (auto& o : ops) o.flags &= (uint8_t)~F_NO_AFFINE;
         if (run_iters < 1) return;
+        const int D = prog.loop_dbls;   // doublings per iteration; the conditional add follows them
         for (int it = 0; it < prog.msm_loop_iters; it++) {
             const bool last_of_run = (it % run_iters) == run_iters - 1 || it == prog.msm_loop_iters - 1;
-            const int t = prog.msm_loop_begin + 3 * it;
-            ops[t].flags |= F_NO_AFFINE;
+            const int t = prog.msm_loop_begin + (D + 1) * it;
+            for (int k = 0; k < D - 1; k++) ops[t + k].flags |= F_NO_AFFINE;
             if (!last_of_run) {
-                ops[t + 1].flags |= F_NO_AFFINE;
-                ops[t + 2].flags |= F_NO_AFFINE;
+                ops[t + D - 1].flags |= F_NO_AFFINE;
+                ops[t + D].flags |= F_NO_AFFINE;
             }
         }
+        // the fixed-base windows are expanded as ONE run per signature (body_expand_fb_run): none of their results
+        // needs affine coordinates in memory, provided the whole chain is one phase-A piece
+        if (mark_fb && prog.fb_begin >= 0)
+            for (int w = 0; w < prog.fb_windows; w++) ops[prog.fb_begin + w].flags |= F_NO_AFFINE;
     }
 
     static constexpr int AUX_KIND_CP_WINDOW = 16, AUX_KIND_CP_BITS = 17, AUX_KIND_CP_BIT = 18;   // p2e_aux_desc kinds (no k_aux pass yet)
@@ -508,6 +520,7 @@ private:
     static constexpr u32 SLOT_P_PLACEHOLDER = 0xFFFF00, SLOT_SP_PLACEHOLDER = 0xFFFF01;
     u32 col_ = 0, aux_col_ = 0, split4_col_ = 0;
     bool generic_ = false;
+    int32_t loop_begin_ = 0, loop_iters_ = 0;   // curve_scalar_mul_windowed's loop (a curve program's Program::msm_loop_*)
     u32 id_zero_ = CONSTV_ZERO, id_a_ = CONSTV_ZERO, id_b_ = CONSTV_B7;
     int id_rando_ = CONST_RANDO, id_neg_rando_ = CONST_NEG_RANDO;
     // built-in-generator values a curve program's gadgets create: numbered (the operand wiring refers to them) and
@@ -520,7 +533,8 @@ private:
         prog.num_chains = 1;
         prog.chain_begin[0] = 0;
         prog.chain_end[0] = (int)ops.size();
-        prog.msm_loop_begin = prog.msm_loop_iters = 0;
+        prog.msm_loop_begin = loop_begin_;
+        prog.msm_loop_iters = loop_iters_;
         finish();
         for (auto& o : ops)
             if (ref_kind(o.ref2) == R_SELSLOT && (ref_id(o.ref2) & 0xFFFu) == 0xFFFu)

@@ -25,6 +25,7 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
         sb.verify_secp256k1_message_circuit();
     else
         sb.glv_mul_circuit();
+    if (chunk < 0) run_iters = 0;   // the small-batch plan expands op by op (plain op table), as run_program() does
     sb.mark_runs(run_iters);
     const Program& G = sb.prog;
     const host::Consts& C = host::consts();
@@ -103,7 +104,14 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
     if (G.num_chains == 3) {
         chain(G.chain_begin[1], G.chain_end[1], false);
         binv(G.chain_begin[1], G.chain_end[1]);
-        expand(G.chain_begin[1], G.chain_end[1]);
+        if (run_iters > 0 && !quad) {   // the windows as one run per signature, then the unblinding add (k_expand_fb_run)
+            const int t_after = G.fb_begin + G.fb_windows;
+#pragma omp parallel for
+            for (long long i = 0; i < (long long)n; i++) body_expand_fb_run<E>(G, B, (size_t)i, t_after);
+            expand(t_after, G.chain_end[1]);
+        } else {
+            expand(G.chain_begin[1], G.chain_end[1]);
+        }
     }
     {
         const int lo0 = G.chain_begin[0], hi0 = G.chain_end[0], lb = G.msm_loop_begin, iters = G.msm_loop_iters;
@@ -434,28 +442,64 @@ static long run_curve(const host::CurveProgramHost& H, const uint8_t* msg, const
         tb = te - G.cp_table_ops;
     }
     bool table_done = false;
-    auto run_piece = [&](int lo, int hi, bool table) {
+    auto chain_binv = [&](int lo, int hi, bool table_affine) {
 #pragma omp parallel for
         for (long long i = 0; i < (long long)n; i++) {
-            body_chain_range<CV, true>(G, B, (size_t)i, lo, hi, table_done, false);
+            body_chain_range<CV, true>(G, B, (size_t)i, lo, hi, table_affine, false);
             body_batch_inv<CV>(G, B, (size_t)i, lo, hi, true);
+        }
+    };
+    auto expand = [&](int lo, int hi) {
+#pragma omp parallel for
+        for (long long i = 0; i < (long long)n; i++)
             for (int t = lo; t < hi; t++) body_expand<Emit, CV>(G, B, (size_t)i, t);
-        }
-        if (table) table_done = true;
     };
-    auto cut = [&](int lo, int hi, bool table) {
-        if (table) {
-            run_piece(lo, hi, true);
-            return;
+    host::ScheduleBuilder marked;
+    if (piece < 0) {
+        // the large-batch plan of run_curve_program: runs of -piece windows (op table with the run marks), the verifier's
+        // fixed-base windows as one run per signature
+        const int R = -piece, lb = G.msm_loop_begin, iters = G.msm_loop_iters, le = lb + 5 * iters;
+        if (iters <= 0) return -2;
+        marked = sb;
+        marked.mark_runs(R);
+        B.ops = marked.ops.data();
+        if (G.fb_begin >= 0) {
+            const int fe = G.fb_begin + G.fb_windows + 1;
+            chain_binv(G.fb_begin, fe, false);
+#pragma omp parallel for
+            for (long long i = 0; i < (long long)n; i++) body_expand_fb_run<Emit, CV>(G, B, (size_t)i, fe - 1);
+            expand(fe - 1, fe);
         }
-        for (int a = lo; a < hi; a += piece) run_piece(a, a + piece < hi ? a + piece : hi, false);
-    };
-    if (tb >= 0) {
-        cut(0, tb, false);
-        cut(tb, te, true);
-        cut(te, G.num_ops, false);
+        chain_binv(tb, te, false);
+        expand(tb, te);
+        for (int it = 0; it < iters; it += R) {
+            const int it1 = std::min(it + R, iters);
+            const int hi = it1 == iters ? G.num_ops : lb + 5 * it1;
+            chain_binv(lb + 5 * it, hi, true);
+#pragma omp parallel for
+            for (long long i = 0; i < (long long)n; i++) body_expand_run<Emit, CV, 4>(G, B, (size_t)i, it, it1);
+            if (it1 == iters) expand(le, G.num_ops);
+        }
     } else {
-        cut(0, G.num_ops, false);
+        auto run_piece = [&](int lo, int hi, bool table) {
+            chain_binv(lo, hi, table_done);
+            expand(lo, hi);
+            if (table) table_done = true;
+        };
+        auto cut = [&](int lo, int hi, bool table) {
+            if (table) {
+                run_piece(lo, hi, true);
+                return;
+            }
+            for (int a2 = lo; a2 < hi; a2 += piece) run_piece(a2, a2 + piece < hi ? a2 + piece : hi, false);
+        };
+        if (tb >= 0) {
+            cut(0, tb, false);
+            cut(tb, te, true);
+            cut(te, G.num_ops, false);
+        } else {
+            cut(0, G.num_ops, false);
+        }
     }
     long bad = 0;
     for (size_t i = 0; i < n; i++) {
@@ -480,7 +524,7 @@ long emu_curve_program(int kind, int curve, const uint8_t* blind_x, const uint8_
     if (num_gens) *num_gens = (long)H.sb.gens.size();
     if (num_aux) *num_aux = (long)H.sb.aux_tab.num_aux_cols;
     if (n == 0) return 0;
-    if (piece < 1) piece = 32;
+    if (piece == 0) piece = 32;   // piece < 0: the run plan with -piece windows per run
     if (curve == 1) return run_curve<P256>(H, msg, r, s, pkx, pky, cols, n, ld, err, valid, piece);
     return run_curve<Secp256k1>(H, msg, r, s, pkx, pky, cols, n, ld, err, valid, piece);
 }
