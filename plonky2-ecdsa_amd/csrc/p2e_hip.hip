@@ -507,7 +507,12 @@ struct p2e_ctx {
     int msm_pieces = 8, fixed_pieces = 2;   // one Montgomery inversion batch per piece
     int msm_pieces_small = 5, fixed_pieces_small = 1;   // ... of the small-batch plan (fewer launches and inversions)
     int run_iters = 9;                      // MSM-loop iterations per expansion run (0: expand op by op)
-    bool fb_run = true;                     // with runs: the fixed-base windows as one run per signature (k_expand_fb_run)
+    // with runs: the fixed-base windows as one run per signature (k_expand_fb_run).  OFF by default in the built-in
+    // verifier: measured 11.43 / 11.05 ms against 10.86 / 11.28 ms per 2^16 batch (alternating processes on one box) --
+    // the single run has one wave per SIMD and lands in the window where the chains and inversions contend with it
+    // (0.40-0.42 of peak against 0.43-0.47 for the same columns through k_expand); P2E_FB_RUN=1 turns it on.  The
+    // P-256 verifier program uses it (curve_api.inc), where it sits beside a longer windowed chain.
+    bool fb_run = false;
     // A run is walked by ONE lane, so a launch of r runs has only r * n/64 waves: below this batch size the
     // 1024 SIMDs are better filled by one workgroup row per op (2^10 glv_mul fills: 3.0 ms against 9.5 ms)
     size_t runs_min_n = 49152;
@@ -679,7 +684,7 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         int v = atoi(env);
         if (v >= 0 && v <= MSM_DIGITS) c->run_iters = v;
     }
-    if (getenv("P2E_NO_FB_RUN")) c->fb_run = false;
+    if (const char* env = getenv("P2E_FB_RUN")) c->fb_run = atoi(env) != 0;
     if (const char* env = getenv("P2E_RUNS_MIN_N")) c->runs_min_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_QUAD_MAX_N")) c->quad_max_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_EXPAND_LDS_SMALL")) c->expand_lds_small = (unsigned)strtoul(env, nullptr, 10);

@@ -123,6 +123,9 @@ def test_verify_run_expansion_any_run_length(ora, monkeypatch, run_iters):
     import plonky2_ecdsa_amd as p2e
     monkeypatch.setenv("P2E_RUNS_MIN_N", "0")
     monkeypatch.setenv("P2E_RUN_ITERS", str(run_iters))
+    # ... and, for two of the run lengths, the fixed-base windows as one run per signature (k_expand_fb_run: off by
+    # default in this program)
+    monkeypatch.setenv("P2E_FB_RUN", "1" if run_iters in (4, 73) else "0")
     n = 700                                             # two full workgroups (paired stores) + a 188-signature tail
     sigs = p2e.synth_signatures(seed=31 + run_iters, n=n)
     ctx = p2e.Context(device=0, host_pointers=True)

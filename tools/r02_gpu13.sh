@@ -6,7 +6,7 @@ timeout -k 10 700 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_r0
 grep -q "pytest_exit=0" gpurun_out/pytest_gpu_r02c.log || exit 1
 for rep in 1 2; do
   for v in fb nofb; do
-    if [ $v = nofb ]; then export P2E_NO_FB_RUN=1; else unset P2E_NO_FB_RUN; fi
+    if [ $v = fb ]; then export P2E_FB_RUN=1; else unset P2E_FB_RUN; fi
     timeout -k 10 120 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-limb-split --check 0 > gpurun_out/ab_fbrun_${v}_$rep.json 2> gpurun_out/ab_fbrun_${v}_$rep.err
     python - <<PY
 import json
@@ -15,7 +15,7 @@ print("$v $rep", d["value"], d["ms_per_step"], d["median_step_ms"], d["roofline"
 PY
   done
 done
-unset P2E_NO_FB_RUN
+unset P2E_FB_RUN
 timeout -k 10 400 python tools/bench_curve_programs.py 16 > gpurun_out/curve_programs_runs.jsonl 2> gpurun_out/curve_programs_runs.err; echo "exit=$?"
 python - <<'PY'
 import json
