@@ -324,9 +324,13 @@ int p2e_wiring_const(uint32_t id, uint8_t out32[32]);
  * bytes each) as an argument -- the Rust side passes the point its builder drew.  Column order = generator
  * registration order as for the built-in programs (p2e_curve_program_describe / _wiring mirror
  * p2e_schedule_describe / _wiring; constant ids of a program resolve through p2e_curve_program_const: 2c / 2c + 1 =
- * x / y of constant point c, 0x8000 + j = scalar constant j).  The built-in-generator targets of these gadgets are
- * numbered and described (p2e_curve_program_aux_describe; the wiring refers to them) but have no fill pass yet.
- * A program belongs to the context's device; u64 column matrix only. */
+ * x / y of constant point c, 64 + j = scalar constant j).  The other targets of the same circuits have the same three
+ * passes as the built-in programs: p2e_curve_program_aux_witness_batch (built-in-generator targets, layout
+ * p2e_curve_program_aux_describe: kinds 0 split4, 2 fixed-base window, 5 window of the windowed multiplication
+ * [selected x (9), selected y (9), is_zero, should_add, not_b, sum.x*b, sum.y*b, p1.x*not_b, p1.y*not_b], 6 bit split,
+ * 7 bit of curve_scalar_mul [not_bit, sum.x*bit, result.x*not_bit, sum.y*bit, result.y*not_bit]),
+ * p2e_curve_program_gate_internal_batch and p2e_curve_program_ux_witness_batch (+ _ux_describe).
+ * A program belongs to the context's device; u64 column matrix only for the fill. */
 #define P2E_CURVE_SECP256K1 0
 #define P2E_CURVE_P256 1
 #define P2E_CP_WINDOWED_MUL 1
@@ -343,6 +347,19 @@ long p2e_curve_program_describe(const p2e_curve_program *prog, p2e_gen_desc *out
 long p2e_curve_program_wiring(const p2e_curve_program *prog, p2e_gen_wiring *out, size_t cap);
 long p2e_curve_program_aux_describe(const p2e_curve_program *prog, p2e_aux_desc *out, size_t cap);
 int p2e_curve_program_const(const p2e_curve_program *prog, uint32_t id, uint8_t out32[32]);
+long p2e_curve_program_num_gate_cols(const p2e_curve_program *prog);
+long p2e_curve_program_num_ux_cols(const p2e_curve_program *prog);
+long p2e_curve_program_ux_describe(const p2e_curve_program *prog, p2e_ux_desc *out, size_t cap);
+/* inputs as for the program's fill (multiplication programs: the scalar in msg32, r32 = s32 = NULL) */
+long p2e_curve_program_aux_witness_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *msg32, const uint8_t *r32,
+                                         const uint8_t *s32, const uint8_t *pkx32, const uint8_t *pky32, const uint64_t *cols,
+                                         size_t ld, uint64_t *aux, size_t ld_aux, size_t n, uint8_t *err);
+long p2e_curve_program_gate_internal_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint64_t *aux, size_t ld_aux,
+                                           uint64_t *gate, size_t ld_gate, size_t n);
+long p2e_curve_program_ux_witness_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *msg32, const uint8_t *r32,
+                                        const uint8_t *s32, const uint8_t *pkx32, const uint8_t *pky32, const uint64_t *cols,
+                                        size_t ld, const uint64_t *aux, size_t ld_aux, void *ux, int ux_u32, size_t ld_ux, size_t n,
+                                        uint8_t *err);
 /* replaces the run_once bodies of every generator curve_scalar_mul_windowed / curve_scalar_mul registers for a batch
  * of (point, scalar) pairs; cols[num_cols][ld].  valid: always 1 unless flagged (the gadgets connect nothing). */
 long p2e_curve_mul_witness_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *px32, const uint8_t *py32,

@@ -64,6 +64,8 @@ EXPORTS = (
     "p2e_curve_program_create", "p2e_curve_program_destroy", "p2e_curve_program_num_cols", "p2e_curve_program_num_aux_cols",
     "p2e_curve_program_scratch_bytes", "p2e_curve_program_describe", "p2e_curve_program_wiring", "p2e_curve_program_aux_describe",
     "p2e_curve_program_const", "p2e_curve_mul_witness_batch", "p2e_p256_verify_witness_batch", "p2e_synth_signatures_curve",
+    "p2e_curve_program_num_gate_cols", "p2e_curve_program_num_ux_cols", "p2e_curve_program_ux_describe",
+    "p2e_curve_program_aux_witness_batch", "p2e_curve_program_gate_internal_batch", "p2e_curve_program_ux_witness_batch",
 )
 
 
@@ -119,7 +121,9 @@ def lib():
                                                    "p2e_schedule_num_cols", "p2e_aux_describe", "p2e_aux_num_cols", "p2e_compact_layout",
                                                    "p2e_columns_compact", "p2e_compact_to_rows", "p2e_curve_program_num_cols",
                                                    "p2e_curve_program_num_aux_cols", "p2e_curve_program_describe",
-                                                   "p2e_curve_program_wiring", "p2e_curve_program_aux_describe"):
+                                                   "p2e_curve_program_wiring", "p2e_curve_program_aux_describe",
+                                                   "p2e_curve_program_num_gate_cols", "p2e_curve_program_num_ux_cols",
+                                                   "p2e_curve_program_ux_describe"):
                 getattr(_lib, name).restype = C.c_long
         _lib.p2e_curve_program_scratch_bytes.restype = C.c_size_t
     return _lib
@@ -292,6 +296,8 @@ class CurveProgram:
         self._h = h
         self.num_cols = int(ctx._L.p2e_curve_program_num_cols(h))
         self.num_aux_cols = int(ctx._L.p2e_curve_program_num_aux_cols(h))
+        self.num_gate_cols = int(ctx._L.p2e_curve_program_num_gate_cols(h))
+        self.num_ux_cols = int(ctx._L.p2e_curve_program_num_ux_cols(h))
 
     def close(self):
         if getattr(self, "_h", None) and getattr(self._ctx, "_h", None):
@@ -352,6 +358,61 @@ class CurveProgram:
         bad = ctx._check(ctx._L.p2e_curve_mul_witness_batch(ctx._h, self._h, _ptr(px), _ptr(py), _ptr(k), _ptr(cols), C.c_size_t(n),
                                                             C.c_size_t(ld), _ptr(err), _ptr(valid)))
         return cols, err, valid, bad
+
+    def _inputs(self, inputs):
+        """(msg, r, s, pkx, pky) pointers from the program's input tuple: (px, py, k) or (msg, r, s, pkx, pky)"""
+        if len(inputs) == 3:
+            px, py, k = inputs
+            return k, None, None, px, py
+        return tuple(inputs)
+
+    def ux_describe(self):
+        """(first_col, num_cols) of every generator's constraint block (order of describe())."""
+        L = self._ctx._L
+        n = L.p2e_curve_program_ux_describe(self._h, None, C.c_size_t(0))
+        arr = (_UxDesc * n)()
+        L.p2e_curve_program_ux_describe(self._h, arr, C.c_size_t(n))
+        return [(int(d.first_col), int(d.num_cols)) for d in arr]
+
+    def aux_witness_batch(self, inputs, cols, n=None, ld=None, aux=None, err=None):
+        """built-in-generator targets of the program's circuit from its finished witness matrix: (num_aux_cols, n)"""
+        ctx = self._ctx
+        msg, r, s, px, py = self._inputs(inputs)
+        n = n if n is not None else ctx._shape(px)[0]
+        ld = ld if ld is not None else _ld(cols)
+        aux = aux if aux is not None else ctx._cols(self.num_aux_cols, n)
+        err = err if err is not None else ctx._vec(n, np.uint8)
+        bad = ctx._check(ctx._L.p2e_curve_program_aux_witness_batch(ctx._h, self._h, _ptr(msg), _ptr(r), _ptr(s), _ptr(px), _ptr(py),
+                                                                    _ptr(cols), C.c_size_t(ld), _ptr(aux), C.c_size_t(_ld(aux)),
+                                                                    C.c_size_t(n), _ptr(err)))
+        return aux, err, bad
+
+    def gate_internal_batch(self, aux, n=None, gate=None):
+        """gate-internal values of the built-in gates behind the windows, from the aux matrix: (num_gate_cols, n)"""
+        ctx = self._ctx
+        n = n if n is not None else aux.shape[1]
+        gate = gate if gate is not None else ctx._cols(self.num_gate_cols, n)
+        ctx._check(ctx._L.p2e_curve_program_gate_internal_batch(ctx._h, self._h, _ptr(aux), C.c_size_t(_ld(aux)), _ptr(gate),
+                                                                C.c_size_t(_ld(gate)), C.c_size_t(n)))
+        return gate
+
+    def ux_witness_batch(self, inputs, cols, aux, n=None, ld=None, ux=None, err=None, u32=True):
+        """constraint-block (U29 gate) values from the finished witness and aux matrices: (num_ux_cols, n) u32 / u64"""
+        ctx = self._ctx
+        msg, r, s, px, py = self._inputs(inputs)
+        n = n if n is not None else ctx._shape(px)[0]
+        ld = ld if ld is not None else _ld(cols)
+        if ux is None:
+            if ctx.host_pointers:
+                ux = np.zeros((self.num_ux_cols, n), dtype=np.uint32 if u32 else np.uint64)
+            else:
+                import torch
+                ux = torch.empty((self.num_ux_cols, n), dtype=torch.int32 if u32 else torch.int64, device=f"cuda:{ctx.device}")
+        err = err if err is not None else ctx._vec(n, np.uint8)
+        bad = ctx._check(ctx._L.p2e_curve_program_ux_witness_batch(ctx._h, self._h, _ptr(msg), _ptr(r), _ptr(s), _ptr(px), _ptr(py),
+                                                                   _ptr(cols), C.c_size_t(ld), _ptr(aux), C.c_size_t(_ld(aux)), _ptr(ux),
+                                                                   C.c_int(1 if u32 else 0), C.c_size_t(_ld(ux)), C.c_size_t(n), _ptr(err)))
+        return ux, err, bad
 
     def verify_witness_batch(self, msg, r, s, pkx, pky, cols=None, err=None, valid=None, ld=None):
         """verify_p256_message_circuit: (115557, n) columns."""

@@ -31,7 +31,13 @@ constexpr u32 CONSTV_ZERO = 6, CONSTV_B7 = 7, CONSTV_GLV_S = 8, CONSTV_GLV_BETA 
 // columns of the result limbs inside the column block of one curve op (gadgets/curve.rs:160-243 emission order)
 constexpr u32 COL_ADD_X3 = 150, COL_ADD_Y3 = 221, COL_DBL_X3 = 201, COL_DBL_Y3 = 272, COL_CADD_X = 231, COL_CADD_Y = 241;
 
-enum AuxKind : uint8_t { AUX_SPLIT4 = 0, AUX_SPLIT2 = 1, AUX_FBWIN = 2, AUX_MSMDIG = 3, AUX_CNEG = 4 };
+// AUX_CP_*: the curve programs' gadgets (curves.hpp): a window of curve_scalar_mul_windowed, the bit split and one bit
+// of curve_scalar_mul
+enum AuxKind : uint8_t { AUX_SPLIT4 = 0, AUX_SPLIT2 = 1, AUX_FBWIN = 2, AUX_MSMDIG = 3, AUX_CNEG = 4, AUX_CP_WINDOW = 5, AUX_CP_BITS = 6,
+                         AUX_CP_BIT = 7 };
+// scalar constants of a curve program: source code AUX_SRC_CONST | (AUX_GCONST_BASE + j); below it 2c / 2c + 1 = x / y
+// of constant point c
+constexpr u32 AUX_GCONST_BASE = 64;
 
 struct AuxItem {
     uint8_t kind;      // AuxKind
@@ -61,6 +67,7 @@ struct AuxArgs {
     const u32* nar;          // compact source: narrow matrix, its stride, wide columns before column c
     size_t ldn;
     const u32* wide_before;
+    const uint8_t* in[5];    // curve programs: every packed input by INPUT_* slot (in[INPUT_PY] == py)
 };
 
 P2E_HD u64 aux_col(const AuxArgs& A, u32 c, size_t i) {
@@ -266,6 +273,118 @@ P2E_HD void body_aux(const AuxArgs& A, int item, size_t i) {
         }
     }
     e.flush();
+}
+
+// ---- curve programs (curves.hpp): targets may also be caller inputs other than pk.y (the stand-alone multiplications
+// take their scalar as an input), tables are per program ----------------------------------------------------------------
+P2E_HD void aux_load_limbs_cv(const AuxArgs& A, u32 src, size_t i, u64* l, int nl) {
+    if ((src & AUX_SRC_KIND_MASK) == AUX_SRC_INPUT) {
+        const u32* p = reinterpret_cast<const u32*>(A.in[src & 7u] + 32 * i);
+        U256 v;
+        P2E_UNROLL
+        for (int k = 0; k < 8; k++) v.w[k] = p[k];
+        aux_limbs_of(v, l);
+        P2E_UNROLL
+        for (int k = 0; k < NL; k++)
+            if (k >= nl) l[k] = 0;
+    } else if (src & AUX_SRC_CONST) {
+        const u32 id = src & 0xFFFFu;
+        const Aff a = A.cpts[id >> 1];
+        aux_limbs_of(u256_select((id & 1) != 0, a.y, a.x), l);
+        P2E_UNROLL
+        for (int k = 0; k < NL; k++)
+            if (k >= nl) l[k] = 0;   // (the virtual `result` of curve_scalar_mul carries the constant in 9 limbs: nl = 9)
+    } else {
+        P2E_UNROLL
+        for (int k = 0; k < NL; k++) l[k] = k < nl ? aux_col(A, src + (u32)k, i) : 0;
+    }
+}
+template <class E>
+P2E_HD void aux_put_products_cv(E& e, const AuxArgs& A, u32 src, int nl, size_t i, u64 b) {
+    u64 l[NL];
+    aux_load_limbs_cv(A, src, i, l, nl);
+    if (nl == NL)
+        aux_put_select(e, l, NL, b);
+    else
+        aux_put_select(e, l, nl, b);
+}
+template <int WB>
+P2E_HD u32 aux_digit_of_limbs(const u64* l, int t) {
+    const int bit = WB * t, li = bit / BITS, sh = bit % BITS;
+    u32 d = li < NL ? (u32)(l[li] >> sh) : 0u;
+    if (sh + WB > BITS && li + 1 < NL) d |= (u32)l[li + 1] << (BITS - sh);
+    return d & ((1u << WB) - 1);
+}
+template <class E>
+P2E_HD void body_aux_cv(const AuxArgs& A, int item, size_t i) {
+    const AuxItem it = A.items[item];
+    E e = E::at(static_cast<typename E::elem*>(A.aux), A.ald, i, it.aux_col);
+    u64 l[NL];
+    if (it.kind == AUX_SPLIT4 || it.kind == AUX_CP_BITS) {   // gadgets/split_nonnative.rs:25-50 / gadgets/nonnative.rs:566-582
+        aux_load_limbs_cv(A, it.a, i, l, NL);
+        bool bad = false;
+        P2E_UNROLL
+        for (int k = 0; k < NL; k++) {
+            bad = bad || (l[k] >> BITS) != 0;
+            P2E_UNROLL
+            for (int j = 0; j < BITS; j++) e.put((l[k] >> j) & 1);
+        }
+        if (bad) err_or(&A.err[i], ERR_LIMB_RANGE);
+        if (it.kind == AUX_SPLIT4) {
+            P2E_UNROLL
+            for (int t = 0; 4 * t < NL * BITS; t++) {
+                const u32 d = aux_digit_of_limbs<4>(l, t);
+                e.put(d & 3);
+                e.put(d >> 2);
+                e.put(d);
+            }
+            e.flush();
+        } else {
+            e.flush();
+        }
+    } else if (it.kind == AUX_FBWIN) {   // gadgets/curve_fixed_base.rs:56-61 (the scalar is a witness target: u1)
+        aux_load_limbs_cv(A, it.a, i, l, NL);
+        const u32 d = aux_digit_of_limbs<4>(l, (int)it.b);
+        const u64 is_zero = d == 0, should_add = 1 - is_zero;
+        e.put(is_zero);
+        e.put(should_add);
+        const Aff r = A.fbtab[it.b * 16 + d];
+        aux_limbs_of(r.x, l);
+        aux_put_select(e, l, NL, 1);
+        aux_limbs_of(r.y, l);
+        aux_put_select(e, l, NL, 1);
+        e.put(is_zero);   // not(should_add)
+        aux_put_products_cv(e, A, it.sumx, NL, i, should_add);
+        aux_put_products_cv(e, A, it.sumy, NL, i, should_add);
+        aux_put_products_cv(e, A, it.p1x, (int)it.nlx, i, is_zero);
+        aux_put_products_cv(e, A, it.p1y, (int)it.nly, i, is_zero);
+        e.flush();
+    } else if (it.kind == AUX_CP_WINDOW) {   // gadgets/curve_windowed_mul.rs:159-163: random access, is_equal, not, conditional add
+        aux_load_limbs_cv(A, it.a, i, l, NL);
+        const u32 d = aux_digit_of_limbs<4>(l, (int)it.b);
+        aux_load_limbs_cv(A, A.tab->tabx[d], i, l, NL);
+        aux_put_select(e, l, NL, 1);
+        aux_load_limbs_cv(A, A.tab->taby[d], i, l, NL);
+        aux_put_select(e, l, NL, 1);
+        const u64 is_zero = d == 0, should_add = 1 - is_zero;
+        e.put(is_zero);
+        e.put(should_add);
+        e.put(is_zero);   // not(should_add)
+        aux_put_products_cv(e, A, it.sumx, NL, i, should_add);
+        aux_put_products_cv(e, A, it.sumy, NL, i, should_add);
+        aux_put_products_cv(e, A, it.p1x, (int)it.nlx, i, is_zero);
+        aux_put_products_cv(e, A, it.p1y, (int)it.nly, i, is_zero);
+        e.flush();
+    } else {   // AUX_CP_BIT gadgets/curve.rs:258-265: not(bit), sum.x * bit, result.x * not_bit, sum.y * bit, result.y * not_bit
+        aux_load_limbs_cv(A, it.a, i, l, NL);
+        const u64 bit = aux_digit_of_limbs<1>(l, (int)it.b), not_bit = 1 - bit;
+        e.put(not_bit);
+        aux_put_products_cv(e, A, it.sumx, NL, i, bit);
+        aux_put_products_cv(e, A, it.p1x, NL, i, not_bit);
+        aux_put_products_cv(e, A, it.sumy, NL, i, bit);
+        aux_put_products_cv(e, A, it.p1y, NL, i, not_bit);
+        e.flush();
+    }
 }
 
 }  // namespace p2e

@@ -77,7 +77,7 @@ struct CurveProgramHost {
 template <class CV>
 inline void build_curve_program(CurveProgramHost& H, int kind, const Aff& blind) {
     ScheduleBuilder& sb = H.sb;
-    sb.begin_curve_program(kind, CV::a(), CV::b());
+    sb.begin_curve_program(kind, H.curve, CV::a(), CV::b());
     const Aff G = generator_cv<CV>();
     if (kind == CP_SCALAR_MUL) {
         const u32 rando = sb.add_const_point(blind), neg = sb.add_const_point(aff_neg_cv<CV>(blind));
@@ -108,7 +108,7 @@ inline bool make_curve_program(CurveProgramHost& H, int kind, int curve, const A
     if (curve != 0 && curve != 1) return false;
     if (kind == CP_VERIFY && curve != 1) return false;
     H.kind = kind;
-    H.curve = curve;
+    H.curve = curve;   // (read by build_curve_program)
     if (curve == 0)
         build_curve_program<Secp256k1>(H, kind, blind);
     else

@@ -209,11 +209,12 @@ public:
 
     // ---- curve programs (curves.hpp) -----------------------------------------------------------------------
     // Constants of a curve program live in the builder: points gpts[c] (source codes 2c / 2c + 1 as for the built-in
-    // ones), scalar constants gvals[j] (source code 0x8000 + j), the fixed-base table gfbtab of the curve's generator.
+    // ones), scalar constants gvals[j] (source code AUX_GCONST_BASE + j), the fixed-base table gfbtab of the curve's generator.
     std::vector<Aff> gpts, gfbtab;
     std::vector<U256> gvals;
-    void begin_curve_program(int kind, const U256& a, const U256& b) {
+    void begin_curve_program(int kind, int curve, const U256& a, const U256& b) {
         generic_ = true;
+        curve_ = curve;
         prog.cp_kind = kind;
         id_zero_ = add_const_value(u256_zero());
         id_a_ = add_const_value(a);
@@ -221,16 +222,17 @@ public:
     }
     u32 add_const_point(const Aff& a) {
         gpts.push_back(a);
+        assert(2 * gpts.size() <= AUX_GCONST_BASE);
         return (u32)gpts.size() - 1;
     }
     u32 add_const_value(const U256& v) {
         gvals.push_back(v);
-        return 0x8000u + (u32)gvals.size() - 1;
+        return AUX_GCONST_BASE + (u32)gvals.size() - 1;
     }
     // the value behind AUX_SRC_CONST | id in THIS builder's program
     U256 cval(u32 id) const {
         if (!generic_) return const_value(id);
-        if (id >= 0x8000u) return gvals[id - 0x8000u];
+        if (id >= AUX_GCONST_BASE) return gvals[id - AUX_GCONST_BASE];
         return (id & 1) ? gpts[id >> 1].y : gpts[id >> 1].x;
     }
     // curve_neg of a CONSTANT point (gadgets/curve.rs:137-147): neg_nonnative(y) is a subtraction generator (10 columns,
@@ -266,7 +268,11 @@ public:
             precompute_window(p, g, neg_g, pre);
             prog.cp_table_ops = (int32_t)ops.size() - t0;
         }
-        for (int i = 0; i < 16; i++) prog.msm_tab[i] = pre[i].ref;
+        for (int i = 0; i < 16; i++) {
+            prog.msm_tab[i] = pre[i].ref;
+            aux_tab.tabx[i] = pre[i].xcol;
+            aux_tab.taby[i] = pre[i].ycol;
+        }
         prog.cp_rows = CP_WINDOWS;
         loop_begin_ = (int32_t)ops.size();
         loop_iters_ = CP_WINDOWS;
@@ -278,9 +284,17 @@ public:
             // sum.y*b (9), p1.x*not_b, p1.y*not_b]  (random_access first, then is_equal / not: :160-163)
             const u32 base = aux_col_;
             AffinePointTarget r{make_ref(R_MSMTAB, (u32)w), false, AUX_SRC_AUX | base, AUX_SRC_AUX | (base + NL)};
-            const u32 nlx = (u32)result.nlx, nly = (u32)result.nly;
+            AuxItem it = select_item(AUX_CP_WINDOW, result);
+            it.a = n.col;
+            it.b = (u32)w;
+            // the window's index = the third value of its (lower, upper, limb) triple behind the split bits; the random
+            // access comes before is_equal here (:159-161)
+            gate_items.push_back({split4_col_ + (u32)NL * BITS + 3 * (u32)w + 2, num_gate_cols, 1});
+            num_gate_cols += GATE_COLS_PER_WINDOW;
             result = curve_conditional_add(result, r, base + 2 * NL + 2, false);
-            aux_skip(AUX_KIND_CP_WINDOW, 2 * NL + 2 + 1 + 2 * NL + nlx + nly);
+            it.sumx = ops.back().col + COL_ADD_X3;
+            it.sumy = ops.back().col + COL_ADD_Y3;
+            aux(it, 2 * NL + 2 + 1 + 2 * NL + (u32)it.nlx + (u32)it.nly);
         }
         Scope s(this, "unblind");
         AffinePointTarget to_add = curve_neg_const(spm, neg_spm);
@@ -289,7 +303,13 @@ public:
     // gadgets/curve.rs:245-285.  Constants: rando (the rand() point) and its negative
     AffinePointTarget curve_scalar_mul(const AffinePointTarget& p, NonNativeTarget n, u32 rando, u32 neg_rando, bool range_check) {
         assert(n.nl == NL);
-        aux_skip(AUX_KIND_CP_BITS, (u32)n.nl * BITS);   // split_nonnative_to_bits gadgets/nonnative.rs:566-582
+        {   // split_nonnative_to_bits gadgets/nonnative.rs:566-582
+            AuxItem it{};
+            it.kind = AUX_CP_BITS;
+            it.a = n.col;
+            it.nlx = (uint8_t)n.nl;
+            aux(it, (u32)n.nl * BITS);
+        }
         // result: a virtual point connected to the constant (9-limb targets that carry the constant's limbs)
         AffinePointTarget result = constant_affine_point((int)rando);
         result.nlx = result.nly = NL;
@@ -304,8 +324,13 @@ public:
             const u32 slot = ref_id(tp.ref) == SLOT_P_PLACEHOLDER ? 0xFFFu : ref_id(tp.ref);
             assert(slot <= 0xFFFu);
             sel.ref = make_ref(R_SELSLOT, slot | ((u32)i << 12));
+            AuxItem it = select_item(AUX_CP_BIT, result);
+            it.a = n.col;
+            it.b = (u32)i;
             result = curve_op(OP_CADD, result, sel, false, base, 1);
-            aux_skip(AUX_KIND_CP_BIT, 1 + 4 * NL);
+            it.sumx = ops.back().col + COL_ADD_X3;
+            it.sumy = ops.back().col + COL_ADD_Y3;
+            aux(it, 1 + 4 * NL);
             tp = curve_double(tp, false);
         }
         Scope s(this, "unblind");
@@ -515,20 +540,14 @@ public:
             for (int w = 0; w < prog.fb_windows; w++) ops[prog.fb_begin + w].flags |= F_NO_AFFINE;
     }
 
-    static constexpr int AUX_KIND_CP_WINDOW = 16, AUX_KIND_CP_BITS = 17, AUX_KIND_CP_BIT = 18;   // p2e_aux_desc kinds (no k_aux pass yet)
 private:
     static constexpr u32 SLOT_P_PLACEHOLDER = 0xFFFF00, SLOT_SP_PLACEHOLDER = 0xFFFF01;
     u32 col_ = 0, aux_col_ = 0, split4_col_ = 0;
     bool generic_ = false;
+    int curve_ = 0;   // 0 secp256k1, 1 P-256: UxItem::field = 2 * curve + field
     int32_t loop_begin_ = 0, loop_iters_ = 0;   // curve_scalar_mul_windowed's loop (a curve program's Program::msm_loop_*)
     u32 id_zero_ = CONSTV_ZERO, id_a_ = CONSTV_ZERO, id_b_ = CONSTV_B7;
     int id_rando_ = CONST_RANDO, id_neg_rando_ = CONST_NEG_RANDO;
-    // built-in-generator values a curve program's gadgets create: numbered (the operand wiring refers to them) and
-    // described, but no AuxItem: the k_aux pass covers the two built-in programs only
-    void aux_skip(int kind, u32 ncols) {
-        aux_gens.push_back({kind, aux_col_, ncols, label()});
-        aux_col_ += ncols;
-    }
     void finish_curve_program() {
         prog.num_chains = 1;
         prog.chain_begin[0] = 0;
@@ -692,7 +711,7 @@ private:
         for (const GenOp& g : gens) {
             u32 nc = 0;
             UxItem it{};
-            it.field = (uint8_t)g.field;
+            it.field = (uint8_t)(2 * curve_ + g.field);
             it.nops = (uint8_t)g.nops;
             it.range_check = g.range_check ? 1 : 0;
             for (int k = 0; k < 4; k++) {

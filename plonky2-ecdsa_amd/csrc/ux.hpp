@@ -226,4 +226,22 @@ P2E_HD void body_ux(const UxArgs& A, int item, size_t i) {
     if (bad) err_or(&A.err[i], ERR_LIMB_RANGE);
 }
 
+// curve programs (curves.hpp): field 0 / 1 = secp256k1 base / scalar, 2 / 3 = P-256 base / scalar; A.consts is the
+// program's constant array indexed by source id (points at 2c / 2c + 1, scalar constants from AUX_GCONST_BASE)
+template <class E>
+P2E_HD void body_ux_cv(const UxArgs& A, int item, size_t i) {
+    const UxItem it = A.items[item];
+    E e = E::at(static_cast<typename E::elem*>(A.ux), A.uld, i, it.ux_col);
+    bool bad = false;
+    if (it.field == 0)
+        ux_block<ModP>(e, A, it, i, bad);
+    else if (it.field == 1)
+        ux_block<ModN>(e, A, it, i, bad);
+    else if (it.field == 2)
+        ux_block<ModP256>(e, A, it, i, bad);
+    else
+        ux_block<ModN256>(e, A, it, i, bad);
+    if (bad) err_or(&A.err[i], ERR_LIMB_RANGE);
+}
+
 }  // namespace p2e

@@ -557,10 +557,105 @@ int emu_curve_program_const(int kind, int curve, const uint8_t* blind_x, const u
     host::CurveProgramHost H;
     if (!host::make_curve_program(H, kind, curve, blind)) return -1;
     id &= 0xFFFFu;
-    if (id >= 0x8000u ? id - 0x8000u >= H.sb.gvals.size() : (id >> 1) >= H.sb.gpts.size()) return -1;
+    if (id >= AUX_GCONST_BASE ? id - AUX_GCONST_BASE >= H.sb.gvals.size() : (id >> 1) >= H.sb.gpts.size()) return -1;
     const U256 v = H.sb.cval(id);
     memcpy(out32, v.w, 32);
     return 0;
+}
+// built-in-generator / gate-internal / constraint-block values of a curve program from finished matrices (the bodies
+// kc_aux / k_gate / kc_ux run); each returns the matrix' column count (call with n = 0 to query it)
+long emu_curve_aux(int kind, int curve, const uint8_t* blind_x, const uint8_t* blind_y, const uint8_t* msg, const uint8_t* r,
+                   const uint8_t* s, const uint8_t* pkx, const uint8_t* pky, const uint64_t* cols, size_t ld, uint64_t* aux, size_t ald,
+                   size_t n, uint8_t* err) {
+    Aff blind;
+    memcpy(blind.x.w, blind_x, 32);
+    memcpy(blind.y.w, blind_y, 32);
+    host::CurveProgramHost H;
+    if (!host::make_curve_program(H, kind, curve, blind)) return -1;
+    const host::ScheduleBuilder& sb = H.sb;
+    if (n == 0) return (long)sb.aux_tab.num_aux_cols;
+    std::vector<u32> err32(n);
+    AuxArgs A{cols, ld, aux, ald, n, pky, sb.gpts.data(), sb.gfbtab.data(), sb.aux_items.data(), &sb.aux_tab, err32.data(), nullptr, 0, nullptr, {}};
+    A.in[INPUT_PY] = pky;
+    A.in[INPUT_PX] = pkx;
+    A.in[INPUT_MSG] = msg;
+    A.in[INPUT_R] = r ? r : msg;
+    A.in[INPUT_S] = s ? s : msg;
+    for (int item = 0; item < (int)sb.aux_items.size(); item++) {
+#pragma omp parallel for
+        for (long long i = 0; i < (long long)n; i++) body_aux_cv<Emit>(A, item, (size_t)i);
+    }
+    for (size_t i = 0; i < n; i++) err[i] = (uint8_t)err32[i];
+    return (long)sb.aux_tab.num_aux_cols;
+}
+long emu_curve_gate(int kind, int curve, const uint8_t* blind_x, const uint8_t* blind_y, const uint64_t* aux, size_t ald, uint64_t* gate,
+                    size_t gld, size_t n) {
+    Aff blind;
+    memcpy(blind.x.w, blind_x, 32);
+    memcpy(blind.y.w, blind_y, 32);
+    host::CurveProgramHost H;
+    if (!host::make_curve_program(H, kind, curve, blind)) return -1;
+    const host::ScheduleBuilder& sb = H.sb;
+    if (n == 0) return (long)sb.num_gate_cols;
+    GateArgs A{};
+    A.aux = aux;
+    A.ald = ald;
+    A.gate = gate;
+    A.gld = gld;
+    A.n = n;
+    A.items = sb.gate_items.data();
+    A.inv16[0] = 0;
+    for (u64 d = 1; d < 16; d++) {   // d^(p-2) in Goldilocks
+        u64 acc = 1, base = d, e = P_GL - 2;
+        while (e) {
+            if (e & 1) acc = gl_mul(acc, base);
+            base = gl_mul(base, base);
+            e >>= 1;
+        }
+        A.inv16[d] = acc;
+    }
+    for (int item = 0; item < (int)sb.gate_items.size(); item++)
+        for (size_t i = 0; i < n; i++) body_gate<Emit>(A, item, i);
+    return (long)sb.num_gate_cols;
+}
+long emu_curve_ux(int kind, int curve, const uint8_t* blind_x, const uint8_t* blind_y, const uint8_t* msg, const uint8_t* r,
+                  const uint8_t* s, const uint8_t* pkx, const uint8_t* pky, const uint64_t* cols, size_t ld, const uint64_t* aux,
+                  size_t ald, uint64_t* ux, size_t uld, size_t n, uint8_t* err) {
+    Aff blind;
+    memcpy(blind.x.w, blind_x, 32);
+    memcpy(blind.y.w, blind_y, 32);
+    host::CurveProgramHost H;
+    if (!host::make_curve_program(H, kind, curve, blind)) return -1;
+    const host::ScheduleBuilder& sb = H.sb;
+    if (n == 0) return (long)sb.num_ux_cols;
+    std::vector<U256> cv(AUX_GCONST_BASE + sb.gvals.size(), u256_zero());
+    for (size_t k = 0; k < sb.gpts.size(); k++) {
+        cv[2 * k] = sb.gpts[k].x;
+        cv[2 * k + 1] = sb.gpts[k].y;
+    }
+    for (size_t j = 0; j < sb.gvals.size(); j++) cv[AUX_GCONST_BASE + j] = sb.gvals[j];
+    std::vector<u32> err32(n);
+    UxArgs A{};
+    A.cols = cols;
+    A.ld = ld;
+    A.aux = aux;
+    A.ald = ald;
+    A.ux = ux;
+    A.uld = uld;
+    A.n = n;
+    A.in[INPUT_PY] = pky;
+    A.in[INPUT_PX] = pkx;
+    A.in[INPUT_MSG] = msg;
+    A.in[INPUT_R] = r ? r : msg;
+    A.in[INPUT_S] = s ? s : msg;
+    A.consts = cv.data();
+    A.items = sb.ux_items.data();
+    A.err = err32.data();
+#pragma omp parallel for
+    for (long long item = 0; item < (long long)sb.ux_items.size(); item++)
+        for (size_t i = 0; i < n; i++) body_ux_cv<Emit>(A, (int)item, i);
+    for (size_t i = 0; i < n; i++) err[i] = (uint8_t)err32[i];
+    return (long)sb.num_ux_cols;
 }
 int emu_synth_signatures_curve(int curve, uint64_t seed, size_t first, size_t n, uint8_t* msg32, uint8_t* r32, uint8_t* s32,
                                uint8_t* pkx32, uint8_t* pky32) {

@@ -108,6 +108,46 @@ class Emu:
                                              self._p(first), self._p(ncols), self._p(src), self._p(nl), C.c_size_t(ng)) == ng
         return kinds, fields, first, ncols, src, nl
 
+    def _args5(self, args):
+        if len(args) == 3:
+            px, py, k = args
+            return k, None, None, px, py
+        return tuple(args)
+
+    def aux(self, kind, curve, blind, args, cols):
+        """built-in-generator values from a finished witness matrix (the body kc_aux runs): (num_aux_cols, n), err"""
+        b, P, z = blind, self._p, C.c_size_t(0)
+        self.L.emu_curve_aux.restype = C.c_long
+        na = self.L.emu_curve_aux(kind, curve, P(b[0]), P(b[1]), None, None, None, None, None, None, z, None, z, z, None)
+        msg, r, s, px, py = self._args5(args)
+        n = px.shape[0]
+        cols = np.ascontiguousarray(cols)
+        aux, err = np.zeros((na, n), np.uint64), np.zeros(n, np.uint8)
+        self.L.emu_curve_aux(kind, curve, P(b[0]), P(b[1]), P(msg), P(r), P(s), P(px), P(py), P(cols), C.c_size_t(n), P(aux), C.c_size_t(n),
+                             C.c_size_t(n), P(err))
+        return aux, err
+
+    def gate(self, kind, curve, blind, aux):
+        b, P, z = blind, self._p, C.c_size_t(0)
+        self.L.emu_curve_gate.restype = C.c_long
+        ng = self.L.emu_curve_gate(kind, curve, P(b[0]), P(b[1]), None, z, None, z, z)
+        n = aux.shape[1]
+        gate = np.zeros((ng, n), np.uint64)
+        if ng:
+            self.L.emu_curve_gate(kind, curve, P(b[0]), P(b[1]), P(np.ascontiguousarray(aux)), C.c_size_t(n), P(gate), C.c_size_t(n), C.c_size_t(n))
+        return gate
+
+    def ux(self, kind, curve, blind, args, cols, aux):
+        b, P, z = blind, self._p, C.c_size_t(0)
+        self.L.emu_curve_ux.restype = C.c_long
+        nu = self.L.emu_curve_ux(kind, curve, P(b[0]), P(b[1]), None, None, None, None, None, None, z, None, z, None, z, z, None)
+        msg, r, s, px, py = self._args5(args)
+        n = px.shape[0]
+        ux, err = np.zeros((nu, n), np.uint64), np.zeros(n, np.uint8)
+        self.L.emu_curve_ux(kind, curve, P(b[0]), P(b[1]), P(msg), P(r), P(s), P(px), P(py), P(np.ascontiguousarray(cols)), C.c_size_t(n),
+                            P(np.ascontiguousarray(aux)), C.c_size_t(n), P(ux), C.c_size_t(n), C.c_size_t(n), P(err))
+        return ux, err
+
     def const(self, kind, curve, blind, cid):
         out = np.zeros(32, np.uint8)
         assert self.L.emu_curve_program_const(kind, curve, self._p(blind[0]), self._p(blind[1]), C.c_uint32(cid), self._p(out)) == 0
@@ -199,6 +239,30 @@ def test_kernel_bodies_match_the_goldens(name, emu):
         for windows_per_run in (6, 11):
             cols3, _, valid3, _ = emu.run(m["kind"], m["curve"], blind, args, piece=-windows_per_run)
             assert np.array_equal(cols, cols3) and np.array_equal(valid, valid3)
+
+
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_other_targets_of_the_circuits(name, emu):
+    """SURVEY 8(f) ranks 1 and 2 for the rank-4 gadgets: the built-in-generator values (split bits, digits, is_equal /
+    not, random-access selections, bool products) against the gadget walk's own record, the gate-internal values and
+    the constraint-block (U29 gate) values against the constraint replay's -- derived from the finished matrices by the
+    bodies kc_aux / k_gate / kc_ux run."""
+    m = META[name]
+    blind, args = _golden_arrays(name)
+    blind_i, cases, _ = _case_ints(name)
+    cols, _, _, _ = emu.run(m["kind"], m["curve"], blind, args)
+    aux, aerr = emu.aux(m["kind"], m["curve"], blind, args, cols)
+    gate = emu.gate(m["kind"], m["curve"], blind, aux)
+    ux, uerr = emu.ux(m["kind"], m["curve"], blind, args, cols, aux)
+    assert aux.shape[0] == m["num_aux"] and not aerr.any() and not uerr.any()
+    for i, cs in enumerate(m["cases"]):
+        assert _digest(aux[:, i]) == cs["aux_sha256"]
+        if not cs["valid"] or i > 1:
+            continue                                        # (the replay of an invalid signature stops at its last connect)
+        c = _replay(name, cols[:, i], blind_i, cases[i], aux=aux[:, i])
+        assert np.array_equal(gate[:, i], np.asarray(c.gate, np.uint64)) and gate.shape[0] == len(c.gate)
+        assert np.array_equal(ux[:, i], np.asarray(c.ux, np.uint64)) and ux.shape[0] == len(c.ux)
+        assert int(ux[:, i].max()) < 1 << 29
 
 
 def test_kernel_bodies_edge_inputs(emu):
@@ -361,6 +425,47 @@ def test_gpu_ragged_batch_against_the_emulation_and_the_walk(name, gpu, emu):
         assert wiring[g][0] == [(int(src[g, k]), int(nl[g, k])) for k in range(len(wiring[g][0]))]
     assert prog.const(0) == blind_i[0] or m["kind"] == 3
     assert sum(d[2] for d in prog.aux_describe()) == m["num_aux"]
+    prog.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_gpu_other_targets_of_the_circuits(name, gpu, emu):
+    """aux / gate-internal / constraint-block matrices of a ragged batch from the library's own witness matrix, against
+    the CPU-compiled bodies on every column and against the constraint replay on two signatures (which recomputes all
+    three from the GPU's hot-path columns alone)"""
+    p2e, torch, ctx = gpu
+    m = META[name]
+    cv = CURVES[m["curve"]]
+    blind_i = cv.mul(0xBEEF + m["kind"], cv.g)
+    blind = (np.frombuffer(blind_i[0].to_bytes(32, "little"), np.uint8).copy(), np.frombuffer(blind_i[1].to_bytes(32, "little"), np.uint8).copy())
+    n = 300
+    sig = p2e.synth_signatures_curve(m["curve"], seed=77 + m["kind"], n=n)
+    args = sig if m["kind"] == 3 else (sig[3], sig[4], sig[0])
+    prog = p2e.CurveProgram(ctx, m["kind"], m["curve"], blind_i)
+    dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in args]
+    cols, err, valid, bad = prog.mul_witness_batch(*dev) if m["kind"] != 3 else prog.verify_witness_batch(*dev)
+    aux, aerr, abad = prog.aux_witness_batch(dev, cols)
+    ux32, uerr, ubad = prog.ux_witness_batch(dev, cols, aux, u32=True)
+    ux64, _, _ = prog.ux_witness_batch(dev, cols, aux, u32=False)
+    gate = prog.gate_internal_batch(aux) if prog.num_gate_cols else None
+    torch.cuda.synchronize()
+    assert bad == abad == ubad == 0
+    h_cols, h_aux = cols.cpu().numpy().view(np.uint64), aux.cpu().numpy().view(np.uint64)
+    e_aux, _ = emu.aux(m["kind"], m["curve"], blind, args, h_cols)
+    assert np.array_equal(h_aux, e_aux)
+    e_ux, _ = emu.ux(m["kind"], m["curve"], blind, args, h_cols, h_aux)
+    assert np.array_equal(ux64.cpu().numpy().view(np.uint64), e_ux)
+    assert np.array_equal(ux32.cpu().numpy().view(np.uint32).astype(np.uint64), e_ux)
+    assert (prog.num_aux_cols, prog.num_ux_cols) == (e_aux.shape[0], e_ux.shape[0])
+    assert sum(nc for _, nc in prog.ux_describe()) == prog.num_ux_cols
+    if gate is not None:
+        assert np.array_equal(gate.cpu().numpy().view(np.uint64), emu.gate(m["kind"], m["curve"], blind, h_aux))
+    for i in (0, n - 1):
+        c = _replay(name, h_cols[:, i], blind_i, [_int(a[i]) for a in args], aux=h_aux[:, i])
+        assert np.array_equal(e_ux[:, i], np.asarray(c.ux, np.uint64))
+        if gate is not None:
+            assert np.array_equal(gate.cpu().numpy().view(np.uint64)[:, i], np.asarray(c.gate, np.uint64))
     prog.close()
 
 
