@@ -157,6 +157,17 @@ extern "C" {
     pub fn p2e_curve_program_wiring(prog: *const P2eCurveProgram, out: *mut P2eGenWiring, cap: usize) -> i64;
     pub fn p2e_curve_program_aux_describe(prog: *const P2eCurveProgram, out: *mut P2eAuxDesc, cap: usize) -> i64;
     pub fn p2e_curve_program_const(prog: *const P2eCurveProgram, id: u32, out32: *mut u8) -> i32;
+    pub fn p2e_curve_program_num_gate_cols(prog: *const P2eCurveProgram) -> i64;
+    pub fn p2e_curve_program_num_ux_cols(prog: *const P2eCurveProgram) -> i64;
+    pub fn p2e_curve_program_ux_describe(prog: *const P2eCurveProgram, out: *mut P2eUxDesc, cap: usize) -> i64;
+    pub fn p2e_curve_program_aux_witness_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, msg32: *const u8, r32: *const u8,
+        s32: *const u8, pkx32: *const u8, pky32: *const u8, cols: *const u64, ld: usize, aux: *mut u64, ld_aux: usize, n: usize,
+        err: *mut u8) -> i64;
+    pub fn p2e_curve_program_gate_internal_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, aux: *const u64, ld_aux: usize,
+        gate: *mut u64, ld_gate: usize, n: usize) -> i64;
+    pub fn p2e_curve_program_ux_witness_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, msg32: *const u8, r32: *const u8,
+        s32: *const u8, pkx32: *const u8, pky32: *const u8, cols: *const u64, ld: usize, aux: *const u64, ld_aux: usize,
+        ux: *mut c_void, ux_u32: i32, ld_ux: usize, n: usize, err: *mut u8) -> i64;
     pub fn p2e_curve_mul_witness_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, px32: *const u8, py32: *const u8,
         k32: *const u8, cols: *mut u64, n: usize, ld: usize, err: *mut u8, valid: *mut u8) -> i64;
     pub fn p2e_p256_verify_witness_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, msg32: *const u8, r32: *const u8,
