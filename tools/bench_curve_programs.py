@@ -72,5 +72,36 @@ for curve, cname in ((p2e.CURVE_SECP256K1, "secp256k1"), (p2e.CURVE_P256, "p256"
                                            "achieved": round(alg / tot_ms / 1e6, 1), "peak": PEAK, "unit": "GB/s",
                                            "frac": round(alg / tot_ms / 1e6 / PEAK, 4), "per_kernel": per_kernel},
                               "scalar_ms": round(p0["scalar"], 3), "scratch_GB": round(prog.scratch_bytes(n) / 1e9, 2)}), flush=True)
+            if os.environ.get("CP_PASSES") and lg <= 14:
+                # the three streaming passes over the finished matrix (aux -> gate-internal -> U29 blocks): wall time of
+                # each synchronous call, algorithmic bytes = what the pass must read + write
+                inputs = sig if kind == p2e.CP_VERIFY else (sig[3], sig[4], sig[0])
+                aux = torch.empty((prog.num_aux_cols, n), dtype=torch.int64, device="cuda")
+                ux = torch.empty((prog.num_ux_cols, n), dtype=torch.int32, device="cuda")
+
+                def wall(fn):
+                    fn()
+                    torch.cuda.synchronize()
+                    ts2 = []
+                    for _ in range(reps):
+                        t = time.perf_counter()
+                        fn()
+                        torch.cuda.synchronize()
+                        ts2.append((time.perf_counter() - t) * 1e3)
+                    return sorted(ts2)[len(ts2) // 2]
+                ms_aux = wall(lambda: prog.aux_witness_batch(inputs, cols[:, :n], n=n, ld=ld, aux=aux, err=err))
+                ms_ux = wall(lambda: prog.ux_witness_batch(inputs, cols[:, :n], aux, n=n, ld=ld, ux=ux, err=err, u32=True))
+                rec = {"program": kname, "curve": cname, "n": n, "passes": {
+                    "kc_aux": {"cols": prog.num_aux_cols, "ms": round(ms_aux, 3), "written_GBps": round(prog.num_aux_cols * 8 * n / ms_aux / 1e6, 1)},
+                    "kc_ux (u32)": {"cols": prog.num_ux_cols, "ms": round(ms_ux, 3), "written_GBps": round(prog.num_ux_cols * 4 * n / ms_ux / 1e6, 1),
+                                    "frac_hbm_peak_written": round(prog.num_ux_cols * 4 * n / ms_ux / 1e6 / PEAK, 4)}}}
+                if prog.num_gate_cols:
+                    gate = torch.empty((prog.num_gate_cols, n), dtype=torch.int64, device="cuda")
+                    ms_gate = wall(lambda: prog.gate_internal_batch(aux, n=n, gate=gate))
+                    rec["passes"]["k_gate"] = {"cols": prog.num_gate_cols, "ms": round(ms_gate, 3),
+                                               "written_GBps": round(prog.num_gate_cols * 8 * n / ms_gate / 1e6, 1)}
+                    del gate
+                print(json.dumps(rec), flush=True)
+                del aux, ux
             del cols, sig
         prog.close()
