@@ -577,8 +577,54 @@ template <>
 P2E_HD void reduce16<ModN, false>(const u32* prod, u32* r, u32* q) { reduce_wide<ModN, 8, false>(prod, r, q); }
 template <>
 P2E_HD void reduce16<ModN, true>(const u32* prod, u32* r, u32* q) { reduce_wide<ModN, 8, true>(prod, r, q); }
+// x mod p for P-256's p = 2^256 - 2^224 + 2^192 + 2^96 - 1 without a multiplication: the NIST fast reduction (FIPS 186-4
+// D.2.3), r = s1 + 2 s2 + 2 s3 + s4 + s5 - s6 - s7 - s8 - s9 over the 32-bit words c0 .. c15 of x, written out per
+// result word as signed word sums.  The sum lies in (-5p, 5p): its signed overflow `top` is folded back twice through
+// 2^256 = p + (2^224 - 2^192 - 2^96 + 1) -- |top| <= 7 leaves at most +-1 after the first fold and nothing after the
+// second -- and one conditional subtraction canonicalises.  No quotient comes out of it: the chains and inversions use
+// this form (fe_mul / fe_sqr), the witness generators keep reduce_barrett, which yields floor(x / p) as well.
+P2E_HD void reduce_p256_solinas(const u32* c /*16*/, u32* r /*8*/) {
+    i64 s[8];
+    s[0] = (i64)c[0] + c[8] + c[9] - c[11] - c[12] - c[13] - c[14];
+    s[1] = (i64)c[1] + c[9] + c[10] - c[12] - c[13] - c[14] - c[15];
+    s[2] = (i64)c[2] + c[10] + c[11] - c[13] - c[14] - c[15];
+    s[3] = (i64)c[3] + 2 * ((i64)c[11] + c[12]) + c[13] - c[15] - c[8] - c[9];
+    s[4] = (i64)c[4] + 2 * ((i64)c[12] + c[13]) + c[14] - c[9] - c[10];
+    s[5] = (i64)c[5] + 2 * ((i64)c[13] + c[14]) + c[15] - c[10] - c[11];
+    s[6] = (i64)c[6] + 3 * (i64)c[14] + 2 * (i64)c[15] + c[13] - c[8] - c[9];
+    s[7] = (i64)c[7] + 3 * (i64)c[15] + c[8] - c[10] - c[11] - c[12] - c[13];
+    u32 t[8];
+    i64 k = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) {
+        k += s[i];
+        t[i] = (u32)k;
+        k >>= 32;   // arithmetic: the running carry is signed
+    }
+    P2E_UNROLL
+    for (int pass = 0; pass < 2; pass++) {   // value = t + k * 2^256 == t + k * (2^224 - 2^192 - 2^96 + 1)  (mod p)
+        const i64 top = k;
+        k = 0;
+        P2E_UNROLL
+        for (int i = 0; i < 8; i++) {
+            k += (i64)t[i] + ((i == 0 || i == 7) ? top : (i == 3 || i == 6) ? -top : 0);
+            t[i] = (u32)k;
+            k >>= 32;
+        }
+    }
+    // now 0 <= t < 2^256 < 2p
+    u32 w[8];
+    u32 br = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) w[i] = subb32(t[i], ModP256::m(i), br);
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) r[i] = br ? t[i] : w[i];
+}
 template <>
-P2E_HD void reduce16<ModP256, false>(const u32* prod, u32* r, u32* q) { reduce_barrett<ModP256, 8, false>(prod, r, q); }
+P2E_HD void reduce16<ModP256, false>(const u32* prod, u32* r, u32* q) {
+    (void)q;
+    reduce_p256_solinas(prod, r);
+}
 template <>
 P2E_HD void reduce16<ModP256, true>(const u32* prod, u32* r, u32* q) { reduce_barrett<ModP256, 8, true>(prod, r, q); }
 template <>

@@ -657,6 +657,40 @@ long emu_curve_ux(int kind, int curve, const uint8_t* blind_x, const uint8_t* bl
     for (size_t i = 0; i < n; i++) err[i] = (uint8_t)err32[i];
     return (long)sb.num_ux_cols;
 }
+// P-256 base field: the multiplication-free reduction of the chains (reduce_p256_solinas) against the Barrett reduction
+// of the witness generators on `count` products of random and structured operands and on raw 512-bit values; returns
+// the number of mismatches
+long emu_p256_reduce_selfcheck(long count, uint64_t seed) {
+    host::SplitMix64 rng{seed};
+    long bad = 0;
+    const u32 edge[6] = {0u, 1u, 0xFFFFFFFFu, 0xFFFFFFFEu, 0x80000000u, 0x7FFFFFFFu};
+    for (long it = 0; it < count; it++) {
+        u32 prod[16];
+        if (it % 3 == 0) {   // a raw 512-bit value built from edge words and random words
+            for (int k = 0; k < 16; k++) prod[k] = (rng.next() & 1) ? edge[rng.next() % 6] : (u32)rng.next();
+        } else {             // a product of two field elements (canonical, or structured near 0 / p)
+            U256 a, b;
+            for (int k = 0; k < 8; k++) {
+                a.w[k] = (it % 3 == 1) ? (u32)rng.next() : edge[rng.next() % 6];
+                b.w[k] = (u32)rng.next();
+            }
+            a = fe_canon<ModP256>(a);
+            b = fe_canon<ModP256>(b);
+            if (it % 7 == 2)
+                for (int k = 0; k < 8; k++) b.w[k] = ModP256::m(k) - (k == 0 ? 1u + (u32)(it & 3) : 0u);   // p - 1 .. p - 4
+            mul_wide<8, 8>(a.w, b.w, prod);
+        }
+        u32 r1[8], r2[8];
+        reduce_p256_solinas(prod, r1);
+        reduce_barrett<ModP256, 8, false>(prod, r2, nullptr);
+        for (int k = 0; k < 8; k++)
+            if (r1[k] != r2[k]) {
+                bad++;
+                break;
+            }
+    }
+    return bad;
+}
 int emu_synth_signatures_curve(int curve, uint64_t seed, size_t first, size_t n, uint8_t* msg32, uint8_t* r32, uint8_t* s32,
                                uint8_t* pkx32, uint8_t* pky32) {
 #pragma omp parallel for

@@ -350,6 +350,13 @@ def test_p256_field_arithmetic_against_bigints(emu):
         assert np.array_equal(cols[:, i], np.asarray(ref, np.uint64)), i
 
 
+def test_p256_multiplication_free_reduction_against_barrett(emu):
+    """csrc/fe.hpp reduce_p256_solinas (the chains' and inversions' reduction: NIST fast reduction, no quotient) against
+    reduce_barrett on 2 000 000 products of random / structured operands and raw 512-bit values"""
+    emu.L.emu_p256_reduce_selfcheck.restype = C.c_long
+    assert emu.L.emu_p256_reduce_selfcheck(C.c_long(2000000), C.c_uint64(2024)) == 0
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def gpu():
