@@ -84,7 +84,9 @@ size_t p2e_scratch_bytes(int program /*0 verify, 1 glv_mul*/, size_t n);
  * chain, trailing adds) and/or k_expand_runs (runs of MSM-loop iterations).
  * out[0] = ms of the scalar kernel, out[4] = ms of the whole call;
  * out[1], out[2], out[3] = k_expand: launches, witness columns per signature they wrote, summed ms;
- * out[5], out[6], out[7] = the same three for k_expand_runs.  Returns the number written (<= 8). */
+ * out[5], out[6], out[7] = the same three for k_expand_runs; out[8], out[9], out[10] = for k_expand_fb_run (the
+ * fixed-base windows as one run per signature: curve programs, and the verifier under P2E_FB_RUN=1).  The curve
+ * programs report their kc_* kernels in the same slots.  Returns the number written (<= 12). */
 int p2e_last_phase_ms(p2e_ctx *ctx, float *out, int cap);
 
 /* ---- single generators (one reference run_once body each) ----------------------------------------- */
