@@ -11,4 +11,4 @@ trap 'cp /tmp/p2e_emu_orig.so tests/emu/libp2e_emu.so; cp /tmp/p2e_oracle_orig.s
 (cd tests/emu && g++ -std=c++17 $FLAGS -Wall -Wno-unused-function -o libp2e_emu.so p2e_emu.cpp)
 (cd oracle && gcc -std=gnu11 $FLAGS -Wall -Wextra -o libp2e_oracle.so p2e_oracle.c)
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
-    python -m pytest tests/test_oracle.py tests/test_host.py -x -q -m "not gpu" -k "not c_client and not bingcd_inversion_round"
+    python -m pytest tests/test_oracle.py tests/test_host.py tests/test_curve_programs.py -x -q -m "not gpu" -k "not c_client and not bingcd_inversion_round and not against_barrett"
