@@ -103,6 +103,9 @@ __global__ __launch_bounds__(BS) void k_batch_inv(Program G, Buffers B, int lo, 
 // op lo + blockIdx.y
 template <int MODE>
 __global__ __launch_bounds__(BS) void k_expand(Program G, Buffers B, int lo, size_t first) {
+#ifdef P2E_EXPAND_PRIO
+    __builtin_amdgcn_s_setprio(P2E_EXPAND_PRIO);   // experiment: issue priority of the expansion waves
+#endif
     size_t i = lane_sig<(MODE & 1) != 0>(first);
 #ifdef P2E_LDS_FBTAB
     // experiment: the 16 table entries of this op's window staged in LDS (one op per workgroup row)
@@ -119,6 +122,9 @@ __global__ __launch_bounds__(BS) void k_expand(Program G, Buffers B, int lo, siz
 // runs of MSM-loop iterations: run blockIdx.y of the launch covers iterations [it_first + y*R, +R) capped at it_end
 template <int MODE>
 __global__ __launch_bounds__(BS) void k_expand_runs(Program G, Buffers B, int it_first, int run_iters, int it_end, size_t first) {
+#ifdef P2E_EXPAND_PRIO
+    __builtin_amdgcn_s_setprio(P2E_EXPAND_PRIO);
+#endif
     size_t i = lane_sig<(MODE & 1) != 0>(first);
     int it0 = it_first + (int)blockIdx.y * run_iters;
     int it1 = it0 + run_iters < it_end ? it0 + run_iters : it_end;
