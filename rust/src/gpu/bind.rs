@@ -89,3 +89,53 @@ pub fn wire_map_of(binding: &HotPathBinding, degree: usize) -> Vec<P2eWireMapEnt
         })
         .collect()
 }
+
+/// One built circuit of `verify_p256_message_circuit` (gadgets/ecdsa.rs:55-78): its hot-path output targets in
+/// registration order (len == 115 557 = `p2e_curve_program_num_cols`) and the library's program object, which carries
+/// the point `precompute_window` drew with `rand()` while THIS circuit was built (gadgets/curve_windowed_mul.rs:57).
+pub struct P256Binding {
+    pub targets: Vec<Target>,
+    pub program: *mut P2eCurveProgram,
+}
+
+/// `blind` = that point (the builder wrapper kept it).  Call once per built circuit; free with
+/// `p2e_curve_program_destroy`.
+pub fn bind_p256_verifier(ctx: *mut P2eCtx, targets: Vec<Target>, blind_x: &BigUint, blind_y: &BigUint) -> Result<P256Binding> {
+    let (bx, by) = (pack32(std::iter::once(blind_x.clone()), 1), pack32(std::iter::once(blind_y.clone()), 1));
+    let mut program = std::ptr::null_mut();
+    let rc = unsafe { p2e_curve_program_create(ctx, P2E_CP_VERIFY, P2E_CURVE_P256, bx.as_ptr(), by.as_ptr(), &mut program) };
+    ensure!(rc == 0, "p2e: {}", unsafe { CStr::from_ptr(p2e_last_error()) }.to_string_lossy());
+    ensure!(targets.len() as i64 == unsafe { p2e_curve_program_num_cols(program) });
+    Ok(P256Binding { targets, program })
+}
+
+/// The P-256 counterpart of `fill_partial_witnesses` (same pre-seeding, same error mapping).
+pub fn fill_partial_witnesses_p256<F: RichField>(
+    binding: &P256Binding,
+    ctx: *mut P2eCtx,
+    sigs: &[VerifyInput],
+    pws: &mut [PartialWitness<F>],
+) -> Result<()> {
+    let n = sigs.len();
+    let ncols = binding.targets.len();
+    ensure!(pws.len() == n);
+    let msg = pack32(sigs.iter().map(|s| s.msg.clone()), n);
+    let r = pack32(sigs.iter().map(|s| s.r.clone()), n);
+    let s = pack32(sigs.iter().map(|s| s.s.clone()), n);
+    let px = pack32(sigs.iter().map(|s| s.pk_x.clone()), n);
+    let py = pack32(sigs.iter().map(|s| s.pk_y.clone()), n);
+    let mut cols = vec![0u64; ncols * n];
+    let (mut err, mut valid) = (vec![0u8; n], vec![0u8; n]);
+    let rc = unsafe {
+        p2e_p256_verify_witness_batch(ctx, binding.program, msg.as_ptr(), r.as_ptr(), s.as_ptr(), px.as_ptr(), py.as_ptr(),
+                                      cols.as_mut_ptr(), n, n, err.as_mut_ptr(), valid.as_mut_ptr())
+    };
+    ensure!(rc >= 0, "p2e: {}", unsafe { CStr::from_ptr(p2e_last_error()) }.to_string_lossy());
+    for i in 0..n {
+        ensure!(err[i] == 0, "signature {i}: witness generation error bits {:#x}", err[i]);
+        for (c, t) in binding.targets.iter().enumerate() {
+            pws[i].set_target(*t, F::from_canonical_u64(cols[c * n + i]))?;
+        }
+    }
+    Ok(())
+}

@@ -518,3 +518,34 @@ def test_gpu_curve_program_misuse(gpu):
     torch.cuda.synchronize()
     assert bad == 0
     prog.close()
+
+
+@pytest.mark.gpu
+def test_gpu_curve_program_host_pointer_mode_and_failed_allocation(emu):
+    """P2E_CTX_HOST_POINTERS: numpy in, numpy out through the library's staging buffers (the path a ctypes-only caller
+    takes); an impossible batch size fails with a status (P2E_E_NOMEM = -4), frees what it staged, and the next call on
+    the same context succeeds"""
+    import plonky2_ecdsa_amd as p2e
+    cv = R.P256
+    blind_i = cv.mul(0xABCDEF, cv.g)
+    blind = (np.frombuffer(blind_i[0].to_bytes(32, "little"), np.uint8).copy(), np.frombuffer(blind_i[1].to_bytes(32, "little"), np.uint8).copy())
+    ctx = p2e.Context(device=0, host_pointers=True)
+    prog = p2e.CurveProgram(ctx, p2e.CP_VERIFY, p2e.CURVE_P256, blind_i)
+    n = 70
+    sig = p2e.synth_signatures_curve(p2e.CURVE_P256, seed=3, n=n)
+    cols, err, valid, bad = prog.verify_witness_batch(*sig)
+    want, _, wvalid, _ = emu.run(p2e.CP_VERIFY, p2e.CURVE_P256, blind, sig)
+    assert bad == 0 and np.array_equal(np.asarray(cols).view(np.uint64), want) and np.array_equal(np.asarray(valid), wvalid)
+    aux, aerr, abad = prog.aux_witness_batch(sig, cols)
+    assert abad == 0 and np.array_equal(np.asarray(aux).view(np.uint64), emu.aux(p2e.CP_VERIFY, p2e.CURVE_P256, blind, sig, want)[0])
+    # a batch whose scratch cannot be allocated: claim 2^36 signatures with buffers the call never gets to touch
+    huge = 1 << 36
+    L = ctx._L
+    L.p2e_p256_verify_witness_batch.restype = C.c_long
+    rc = L.p2e_p256_verify_witness_batch(ctx._h, prog._h, *[a.ctypes.data_as(C.c_void_p) for a in sig],
+                                         np.asarray(cols).ctypes.data_as(C.c_void_p), C.c_size_t(huge), C.c_size_t(huge),
+                                         np.asarray(err).ctypes.data_as(C.c_void_p), np.asarray(valid).ctypes.data_as(C.c_void_p))
+    assert rc == -4, (rc, L.p2e_last_error())
+    cols2, _, valid2, bad2 = prog.verify_witness_batch(*sig)
+    assert bad2 == 0 and np.array_equal(np.asarray(cols2).view(np.uint64), want)
+    prog.close()
