@@ -42,6 +42,8 @@ extern "C" {
 
 #define P2E_FIELD_BASE 0   /* plonky2 Secp256K1Base   (point coordinates)      */
 #define P2E_FIELD_SCALAR 1 /* plonky2 Secp256K1Scalar (msg, r, s, u1, u2, k1, k2) */
+#define P2E_FIELD_P256_BASE 2   /* the crate's P256Base   (field/p256_base.rs)   -- single-generator entry points only */
+#define P2E_FIELD_P256_SCALAR 3 /* the crate's P256Scalar (field/p256_scalar.rs) */
 
 /* per-element error bits */
 #define P2E_ERR_LIMB_RANGE 1       /* limb >= 2^29: gates/mul_nonnative.rs:262,271,275-276; biguint.rs:456,473 */

@@ -32,7 +32,9 @@ MASK29 = (1 << BITS) - 1
 
 FIELD_BASE = 0
 FIELD_SCALAR = 1
-MODULI = {FIELD_BASE: P, FIELD_SCALAR: N}
+FIELD_P256_BASE = 2
+FIELD_P256_SCALAR = 3
+MODULI = {FIELD_BASE: P, FIELD_SCALAR: N}     # secp256k1; the P-256 pair is added below (MODULI[2], MODULI[3])
 
 
 def _u64le(ws):
@@ -241,6 +243,7 @@ P256 = Curve("p256", P256_P, P256_N, P256_P - 3,
              (0x6B17D1F2E12C4247F8BCE6E563A440F277037D812DEB33A0F4A13945D898C296,
               0x4FE342E2FE1A7F9B8EE7EB4A7C0F9E162BCE33576B315ECECBB6406837BF51F5))
 CURVES = {"secp256k1": SECP256K1, "p256": P256}
+MODULI[FIELD_P256_BASE], MODULI[FIELD_P256_SCALAR] = P256_P, P256_N
 
 
 def rando_point():

@@ -33,6 +33,7 @@ LIB_PATH = os.environ.get("P2E_LIB") or os.path.join(_HERE, "libp2e_hip.so")
 
 FIELD_BASE = 0    # plonky2 Secp256K1Base
 FIELD_SCALAR = 1  # plonky2 Secp256K1Scalar
+FIELD_P256_BASE, FIELD_P256_SCALAR = 2, 3   # the crate's P256Base / P256Scalar (single-generator entry points)
 ERR_LIMB_RANGE, ERR_VALUE_GE_2_256, ERR_INVERSE_OF_ZERO, ERR_CARRY_RANGE, ERR_QUOTIENT_RANGE = 1, 2, 4, 8, 16
 ERR_DIVISION_BY_ZERO = 32
 CTX_HOST_POINTERS, CTX_ASYNC = 1, 2

@@ -566,6 +566,46 @@ P2E_HD void reduce_barrett(const u32* prod /*8+NH*/, u32* r /*8*/, u32* q /*9 or
     }
 }
 
+// The same for products beyond 2^512 (the raw MulNonnative entry point takes 261-bit operands: NH = 10).  There mu's
+// rounding error is no longer below one: the first estimate can be short by up to 2^(32 NH - 256) multiples of m.  So:
+// one estimate WITHOUT the final corrections -- the partial remainder R = prod - q3 m is below (2^(32 NH - 256) + 3) m and
+// fits 9 words -- then the plain reduction of R (a 9-word value: its own estimate is within two of the truth).
+template <class MOD, int NH, bool WANT_Q>
+P2E_HD void reduce_barrett_wide(const u32* prod /*8+NH*/, u32* r /*8*/, u32* q /*9 or null*/) {
+    static_assert(NH > 8 && NH <= 10, "products of operands up to 9 words");
+    constexpr int NQ = NH + 1;
+    u32 muw[9], mw[8];
+    P2E_UNROLL
+    for (int i = 0; i < 9; i++) muw[i] = MOD::mu(i);
+    P2E_UNROLL
+    for (int i = 0; i < 8; i++) mw[i] = MOD::m(i);
+    u32 q2[NQ + 9];
+    mul_wide<NQ, 9>(prod + 7, muw, q2);
+    const u32* q3 = q2 + 9;   // NQ words; only the low 9 can be non-zero when the true quotient fits 9 words
+    u32 r2[9];
+    mul_lo<NQ, 8, 9>(q3, mw, r2);
+    u32 t[9];
+    u32 br = 0;
+    P2E_UNROLL
+    for (int i = 0; i < 9; i++) t[i] = subb32(prod[i], r2[i], br);
+    u32 qe[9];
+    reduce_barrett<MOD, 1, WANT_Q>(t, r, WANT_Q ? qe : nullptr);
+    if (WANT_Q) {
+        u32 c = 0;
+        P2E_UNROLL
+        for (int i = 0; i < 9; i++) q[i] = addc32(q3[i], qe[i], c);
+        // a quotient beyond 9 words (q3's upper words, or the carry) cannot be emitted: saturate so that the caller's
+        // range check on q flags the element
+        u32 hi = c;
+        P2E_UNROLL
+        for (int i = 9; i < NQ; i++) hi |= q3[i];
+        if (hi) {
+            P2E_UNROLL
+            for (int i = 0; i < 9; i++) q[i] = 0xFFFFFFFFu;
+        }
+    }
+}
+
 // 16-word product -> (r, q): specialised path for p, generic fold chain for n
 template <class MOD, bool WANT_Q>
 P2E_HD void reduce16(const u32* prod, u32* r, u32* q);

@@ -1018,7 +1018,7 @@ static inline dim3 grid1(size_t n) { return dim3((unsigned)((n + BS - 1) / BS));
 // ====================================================================================================
 extern "C" long p2e_mul_witness_batch(p2e_ctx* c, int field, const uint64_t* x, const uint64_t* y, uint64_t* r,
                                       uint64_t* q, uint64_t* cs, uint64_t* b, size_t n, size_t ld, uint8_t* err) {
-    if (bad_common(c, n, ld) || !x || !y || !r || !q || !cs || !b || !err || (field != 0 && field != 1)) return P2E_E_INVALID;
+    if (bad_common(c, n, ld) || !x || !y || !r || !q || !cs || !b || !err || (field < 0 || field > 3)) return P2E_E_INVALID;
     if (n == 0) return 0;
     Staged S(c);
     size_t cb = ld * 8;
@@ -1033,8 +1033,12 @@ extern "C" long p2e_mul_witness_batch(p2e_ctx* c, int field, const uint64_t* x, 
     ZERO_COUNTER(c);
     if (field == P2E_FIELD_BASE)
         hipLaunchKernelGGL(k_mul<ModP>, grid1(n), dim3(BS), 0, c->stream, x, y, r, q, cs, b, n, ld, err, c->d_counter);
-    else
+    else if (field == P2E_FIELD_SCALAR)
         hipLaunchKernelGGL(k_mul<ModN>, grid1(n), dim3(BS), 0, c->stream, x, y, r, q, cs, b, n, ld, err, c->d_counter);
+    else if (field == P2E_FIELD_P256_BASE)
+        hipLaunchKernelGGL(k_mul<ModP256>, grid1(n), dim3(BS), 0, c->stream, x, y, r, q, cs, b, n, ld, err, c->d_counter);
+    else
+        hipLaunchKernelGGL(k_mul<ModN256>, grid1(n), dim3(BS), 0, c->stream, x, y, r, q, cs, b, n, ld, err, c->d_counter);
     return S.done(finish_call(c));
 }
 extern "C" long p2e_checksum_witness_batch(p2e_ctx* c, const uint64_t* a, uint64_t* b, size_t n, size_t ld, uint8_t* err) {
@@ -1051,7 +1055,7 @@ extern "C" long p2e_checksum_witness_batch(p2e_ctx* c, const uint64_t* a, uint64
 }
 static long addsub(p2e_ctx* c, int field, bool is_sub, const uint64_t* a, const uint64_t* b, uint64_t* out,
                    uint64_t* ov, size_t n, size_t ld, uint8_t* err) {
-    if (bad_common(c, n, ld) || !a || !b || !out || !ov || !err || (field != 0 && field != 1)) return P2E_E_INVALID;
+    if (bad_common(c, n, ld) || !a || !b || !out || !ov || !err || (field < 0 || field > 3)) return P2E_E_INVALID;
     if (n == 0) return 0;
     Staged S(c);
     a = S.in(a, 9 * ld * 8);
@@ -1066,6 +1070,10 @@ static long addsub(p2e_ctx* c, int field, bool is_sub, const uint64_t* a, const 
     if (field == 0 && is_sub) hipLaunchKernelGGL((k_addsub<ModP, true>), g, bs, 0, c->stream, a, b, out, ov, n, ld, err, c->d_counter);
     if (field == 1 && !is_sub) hipLaunchKernelGGL((k_addsub<ModN, false>), g, bs, 0, c->stream, a, b, out, ov, n, ld, err, c->d_counter);
     if (field == 1 && is_sub) hipLaunchKernelGGL((k_addsub<ModN, true>), g, bs, 0, c->stream, a, b, out, ov, n, ld, err, c->d_counter);
+    if (field == 2 && !is_sub) hipLaunchKernelGGL((k_addsub<ModP256, false>), g, bs, 0, c->stream, a, b, out, ov, n, ld, err, c->d_counter);
+    if (field == 2 && is_sub) hipLaunchKernelGGL((k_addsub<ModP256, true>), g, bs, 0, c->stream, a, b, out, ov, n, ld, err, c->d_counter);
+    if (field == 3 && !is_sub) hipLaunchKernelGGL((k_addsub<ModN256, false>), g, bs, 0, c->stream, a, b, out, ov, n, ld, err, c->d_counter);
+    if (field == 3 && is_sub) hipLaunchKernelGGL((k_addsub<ModN256, true>), g, bs, 0, c->stream, a, b, out, ov, n, ld, err, c->d_counter);
     return S.done(finish_call(c));
 }
 extern "C" long p2e_add_witness_batch(p2e_ctx* c, int field, const uint64_t* a, const uint64_t* b, uint64_t* sum,
@@ -1078,7 +1086,7 @@ extern "C" long p2e_sub_witness_batch(p2e_ctx* c, int field, const uint64_t* a, 
 }
 extern "C" long p2e_add_many_witness_batch(p2e_ctx* c, int field, const uint64_t* s, int k, uint64_t* sum,
                                            uint64_t* ov, size_t n, size_t ld, uint8_t* err) {
-    if (bad_common(c, n, ld) || !s || !sum || !ov || !err || (field != 0 && field != 1) || k < 1 || k > 8) return P2E_E_INVALID;
+    if (bad_common(c, n, ld) || !s || !sum || !ov || !err || (field < 0 || field > 3) || k < 1 || k > 8) return P2E_E_INVALID;
     if (n == 0) return 0;
     Staged S(c);
     s = S.in(s, (size_t)k * 9 * ld * 8);
@@ -1089,13 +1097,17 @@ extern "C" long p2e_add_many_witness_batch(p2e_ctx* c, int field, const uint64_t
     ZERO_COUNTER(c);
     if (field == 0)
         hipLaunchKernelGGL(k_add_many<ModP>, grid1(n), dim3(BS), 0, c->stream, s, k, sum, ov, n, ld, err, c->d_counter);
-    else
+    else if (field == 1)
         hipLaunchKernelGGL(k_add_many<ModN>, grid1(n), dim3(BS), 0, c->stream, s, k, sum, ov, n, ld, err, c->d_counter);
+    else if (field == 2)
+        hipLaunchKernelGGL(k_add_many<ModP256>, grid1(n), dim3(BS), 0, c->stream, s, k, sum, ov, n, ld, err, c->d_counter);
+    else
+        hipLaunchKernelGGL(k_add_many<ModN256>, grid1(n), dim3(BS), 0, c->stream, s, k, sum, ov, n, ld, err, c->d_counter);
     return S.done(finish_call(c));
 }
 extern "C" long p2e_inv_witness_batch(p2e_ctx* c, int field, const uint64_t* x, uint64_t* inv, uint64_t* div,
                                       size_t n, size_t ld, uint8_t* err) {
-    if (bad_common(c, n, ld) || !x || !inv || !div || !err || (field != 0 && field != 1)) return P2E_E_INVALID;
+    if (bad_common(c, n, ld) || !x || !inv || !div || !err || (field < 0 || field > 3)) return P2E_E_INVALID;
     if (n == 0) return 0;
     Staged S(c);
     x = S.in(x, 9 * ld * 8);
@@ -1106,8 +1118,12 @@ extern "C" long p2e_inv_witness_batch(p2e_ctx* c, int field, const uint64_t* x, 
     ZERO_COUNTER(c);
     if (field == 0)
         hipLaunchKernelGGL(k_inv<ModP>, grid1(n), dim3(BS), 0, c->stream, x, inv, div, n, ld, err, c->d_counter);
-    else
+    else if (field == 1)
         hipLaunchKernelGGL(k_inv<ModN>, grid1(n), dim3(BS), 0, c->stream, x, inv, div, n, ld, err, c->d_counter);
+    else if (field == 2)
+        hipLaunchKernelGGL(k_inv<ModP256>, grid1(n), dim3(BS), 0, c->stream, x, inv, div, n, ld, err, c->d_counter);
+    else
+        hipLaunchKernelGGL(k_inv<ModN256>, grid1(n), dim3(BS), 0, c->stream, x, inv, div, n, ld, err, c->d_counter);
     return S.done(finish_call(c));
 }
 extern "C" long p2e_biguint_div_rem_batch(p2e_ctx* c, const uint64_t* a, int na, const uint64_t* b, int nb, uint64_t* div,

@@ -84,7 +84,10 @@ P2E_HD uint8_t prim_mul(const u64* x, const u64* y, u64* r, u64* q, u64* cs, u64
     pack29_wide(x29, xw);
     pack29_wide(y29, yw);
     mul_wide<9, 9>(xw, yw, prod);
-    reduce_wide<MOD, 10, true>(prod, rv.w, qw);
+    if constexpr (MOD::kBarrett)
+        reduce_barrett_wide<MOD, 10, true>(prod, rv.w, qw);
+    else
+        reduce_wide<MOD, 10, true>(prod, rv.w, qw);
     if (qw[8] >> 5) err |= ERR_QUOTIENT_RANGE;  // q does not fit the gate's 9 q wires
     u32 q29[NL], r29[NL];
     split29(rv, r29);

@@ -383,20 +383,35 @@ long emu_aux_num_cols(int program) {
     }                                               \
     return bad;
 long emu_mul(int field, const u64* x, const u64* y, u64* r, u64* q, u64* cs, u64* b, size_t n, size_t ld, uint8_t* err) {
-    LOOP(field ? prim_mul<ModN>(x, y, r, q, cs, b, ld, i) : prim_mul<ModP>(x, y, r, q, cs, b, ld, i))
+    LOOP(field == 3   ? prim_mul<ModN256>(x, y, r, q, cs, b, ld, i)
+         : field == 2 ? prim_mul<ModP256>(x, y, r, q, cs, b, ld, i)
+         : field      ? prim_mul<ModN>(x, y, r, q, cs, b, ld, i)
+                      : prim_mul<ModP>(x, y, r, q, cs, b, ld, i))
 }
 long emu_checksum(const u64* a, u64* b, size_t n, size_t ld, uint8_t* err) { LOOP(prim_checksum(a, b, ld, i)) }
 long emu_add(int field, const u64* a, const u64* b, u64* out, u64* ov, size_t n, size_t ld, uint8_t* err) {
-    LOOP(field ? (prim_addsub<ModN, false>(a, b, out, ov, ld, i)) : (prim_addsub<ModP, false>(a, b, out, ov, ld, i)))
+    LOOP(field == 3   ? (prim_addsub<ModN256, false>(a, b, out, ov, ld, i))
+         : field == 2 ? (prim_addsub<ModP256, false>(a, b, out, ov, ld, i))
+         : field      ? (prim_addsub<ModN, false>(a, b, out, ov, ld, i))
+                      : (prim_addsub<ModP, false>(a, b, out, ov, ld, i)))
 }
 long emu_sub(int field, const u64* a, const u64* b, u64* out, u64* ov, size_t n, size_t ld, uint8_t* err) {
-    LOOP(field ? (prim_addsub<ModN, true>(a, b, out, ov, ld, i)) : (prim_addsub<ModP, true>(a, b, out, ov, ld, i)))
+    LOOP(field == 3   ? (prim_addsub<ModN256, true>(a, b, out, ov, ld, i))
+         : field == 2 ? (prim_addsub<ModP256, true>(a, b, out, ov, ld, i))
+         : field      ? (prim_addsub<ModN, true>(a, b, out, ov, ld, i))
+                      : (prim_addsub<ModP, true>(a, b, out, ov, ld, i)))
 }
 long emu_add_many(int field, const u64* s, int k, u64* out, u64* ov, size_t n, size_t ld, uint8_t* err) {
-    LOOP(field ? prim_add_many<ModN>(s, k, out, ov, ld, i) : prim_add_many<ModP>(s, k, out, ov, ld, i))
+    LOOP(field == 3   ? prim_add_many<ModN256>(s, k, out, ov, ld, i)
+         : field == 2 ? prim_add_many<ModP256>(s, k, out, ov, ld, i)
+         : field      ? prim_add_many<ModN>(s, k, out, ov, ld, i)
+                      : prim_add_many<ModP>(s, k, out, ov, ld, i))
 }
 long emu_inv(int field, const u64* x, u64* inv, u64* div, size_t n, size_t ld, uint8_t* err) {
-    LOOP(field ? prim_inv<ModN>(x, inv, div, ld, i) : prim_inv<ModP>(x, inv, div, ld, i))
+    LOOP(field == 3   ? prim_inv<ModN256>(x, inv, div, ld, i)
+         : field == 2 ? prim_inv<ModP256>(x, inv, div, ld, i)
+         : field      ? prim_inv<ModN>(x, inv, div, ld, i)
+                      : prim_inv<ModP>(x, inv, div, ld, i))
 }
 long emu_div_rem(const u64* a, int na, const u64* b, int nb, u64* div, u64* rem, size_t n, size_t ld, uint8_t* err) {
     LOOP(prim_div_rem(a, na, b, nb, div, rem, ld, i))

@@ -549,3 +549,79 @@ def test_gpu_curve_program_host_pointer_mode_and_failed_allocation(emu):
     cols2, _, valid2, bad2 = prog.verify_witness_batch(*sig)
     assert bad2 == 0 and np.array_equal(np.asarray(cols2).view(np.uint64), want)
     prog.close()
+
+# ---- the crate's generators as stand-alone batch entry points over the P-256 fields (P2E_FIELD_P256_BASE / _SCALAR) ----
+def _p256_generator_cases(field, count, seed):
+    """limb-column operands: random canonical values, values around 0 / m / 2^256, raw 261-bit limb patterns"""
+    m = R.MODULI[field]
+    rng = R.SplitMix64(seed)
+    edge = [0, 1, 2, m - 1, m, m + 1, (1 << 255), (1 << 256) - 1, m // 2, (m + 1) // 2]
+    xs, ys = [], []
+    for i in range(count):
+        a = edge[i % len(edge)] if i % 3 == 0 else rng.below(m)
+        b = edge[(i // len(edge)) % len(edge)] if i % 5 == 0 else rng.below(m)
+        xs.append(R.limbs_of(a, R.NL))
+        ys.append(R.limbs_of(b, R.NL))
+    for i in range(count // 4):                                 # all nine limbs used: operands up to 2^261 - 1
+        xs.append([rng.next() & R.MASK29 if (i + k) % 4 else R.MASK29 for k in range(R.NL)])
+        ys.append([rng.next() & R.MASK29 for k in range(R.NL)])
+    return xs, ys
+
+
+def _check_p256_generators(be, field, count=160):
+    m = R.MODULI[field]
+    xs, ys = _p256_generator_cases(field, count, 1000 + field)
+    cols = lambda ls: np.array(ls, dtype=np.uint64).T.copy()
+    x, y = cols(xs), cols(ys)
+    r, q, cs, b, err = [np.asarray(a) for a in be.mul(field, x, y)]
+    for i, (xl, yl) in enumerate(zip(xs, ys)):
+        try:
+            wr, wq, wcs = R.gen_mul(xl, yl, m)
+            wb = R.gen_checksum(wcs)
+        except R.RefPanic:
+            assert err[i] != 0, ("mul", i)
+            continue
+        assert err[i] == 0 and list(r[:, i]) == wr and list(q[:, i]) == wq and list(cs[:, i]) == wcs and list(b[:, i]) == wb, ("mul", i)
+    for name, gen in (("add", R.gen_add), ("sub", R.gen_sub)):
+        out, ov, err = [np.asarray(a) for a in getattr(be, name)(field, x, y)]
+        for i, (xl, yl) in enumerate(zip(xs, ys)):
+            try:
+                wo, wov = gen(xl, yl, m)
+            except R.RefPanic:
+                assert err[i] != 0, (name, i)
+                continue
+            assert err[i] == 0 and list(out[:, i]) == wo and int(ov[i]) == wov, (name, i)
+    inv, div, err = [np.asarray(a) for a in be.inv(field, x)]
+    for i, xl in enumerate(xs):
+        try:
+            wi, wd = R.gen_inv(xl, m)
+        except R.RefPanic:
+            assert err[i] != 0, ("inv", i)
+            continue
+        assert err[i] == 0 and list(inv[:, i]) == wi and list(div[:, i]) == wd, ("inv", i)
+    n = len(xs) // 4 * 4
+    s4 = np.array([[xs[4 * j + k] for j in range(n // 4)] for k in range(4)], dtype=np.uint64).transpose(0, 2, 1).copy()   # (4, 9, n/4)
+    out, ov, err = [np.asarray(a) for a in be.add_many(field, s4)]
+    for j in range(n // 4):
+        try:
+            wo, wov = R.gen_add_many([xs[4 * j + k] for k in range(4)], m)
+        except R.RefPanic:
+            assert err[j] != 0, ("add_many", j)
+            continue
+        assert err[j] == 0 and list(out[:, j]) == wo and int(ov[j]) == wov, ("add_many", j)
+
+
+@pytest.mark.parametrize("field", [R.FIELD_P256_BASE, R.FIELD_P256_SCALAR])
+def test_generators_over_the_p256_fields_kernel_bodies(field):
+    """MulNonnative + CheckSum, NonNativeAddition / Subtraction / MultipleAdds / Inverse (gates/mul_nonnative.rs:249-324,
+    513-531; gadgets/nonnative.rs:626-645, 792-810, 696-728, 857-872) with FF = P256Base / P256Scalar, incl. the
+    261-bit raw operands of the multiplication gate (reduce_barrett_wide) and every panic of the reference as a flag"""
+    from backends import EmuBackend
+    _check_p256_generators(EmuBackend(), field)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field", [R.FIELD_P256_BASE, R.FIELD_P256_SCALAR])
+def test_gpu_generators_over_the_p256_fields(field):
+    from backends import GpuBackend
+    _check_p256_generators(GpuBackend(), field, count=600)
