@@ -34,6 +34,10 @@ Extra objects on the line:
   cpu_baseline_optimised   the same C code with Montgomery batch inversion across lock-step groups of 256
                signatures (BASELINE.md section 2 variant b): the baseline a careful CPU implementation would set.
   checked_vs_oracle   signatures of the LAST timed output buffer compared column by column with the C oracle.
+  p256_verify  (N = 1) the widened path on the same line: verify_p256_message_circuit (gadgets/ecdsa.rs:55-78) as a curve
+               program, batch 2^16, 115 557 columns per fill: fills/s (median of 5 synchronous calls), whole-fill share of
+               the HBM peak, and the expansion kernels' share from the library's HIP-event pairs.  Outside the timed
+               region of the headline metric; never part of `value`.
 """
 import argparse
 import json
@@ -65,6 +69,49 @@ def usable_cores(omp_max):
     except Exception:
         pass
     return max(1, n)
+
+
+def p256_leg(p2e, torch, ctx, dev, n):
+    """verify_p256_message_circuit witnesses of n synthetic P-256 signatures through the curve-program entry point."""
+    b = p2e.synth_signatures_curve(p2e.CURVE_P256, seed=777, n=1)      # any multiple of G serves as the circuit's rand() point
+    blind = (int.from_bytes(bytes(b[3][0]), "little"), int.from_bytes(bytes(b[4][0]), "little"))
+    prog = p2e.CurveProgram(ctx, p2e.CP_VERIFY, p2e.CURVE_P256, blind)
+    # host-side synthesis of P-256 signatures is two generic scalar multiplications each (no fixed-base table on the host):
+    # 2 048 distinct valid signatures, tiled over the batch (the kernels' work does not depend on the values)
+    distinct = min(n, 2048)
+    base = p2e.synth_signatures_curve(p2e.CURVE_P256, seed=4, n=distinct)
+    sig = [torch.from_numpy(np.tile(a, ((n + distinct - 1) // distinct, 1))[:n].copy()).to(dev) for a in base]
+    ld = n + 16
+    cols = torch.empty((prog.num_cols, ld), dtype=torch.int64, device=dev)
+    err = torch.empty(n, dtype=torch.uint8, device=dev)
+    valid = torch.empty(n, dtype=torch.uint8, device=dev)
+    call = lambda: prog.verify_witness_batch(*sig, cols=cols[:, :n], err=err, valid=valid, ld=ld)[3]
+    bad = call()
+    torch.cuda.synchronize()
+    assert bad == 0 and int(valid.sum()) == n, "synthetic P-256 signatures must all verify"
+    ts, ph = [], []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        call()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t)
+        ph.append(ctx.last_phase_ms())
+    med = sorted(ts)[len(ts) // 2]
+    kinds = (("expand", "kc_expand"), ("runs", "kc_expand_runs"), ("fbrun", "kc_expand_fb_run"))
+    exp_ms = sorted(sum(p[k] for k, _ in kinds) for p in ph)[len(ph) // 2]
+    exp_cols = sum(ph[0][k + "_cols"] for k, _ in kinds)
+    out_bytes = prog.num_cols * 8 * n
+    res = {"workload": f"batch 2^{n.bit_length() - 1} verify_p256_message_circuit fills, 115 557 columns each, curve program (DESIGN.md 5f); "
+                       f"{distinct} distinct valid signatures tiled over the batch",
+           "value": round(n / med, 1), "unit": "fills/s", "ms_per_call": round(med * 1e3, 3),
+           "whole_fill_frac_of_hbm_peak": round(out_bytes / med / 1e9 / HBM_PEAK_GBS, 4),
+           "roofline": {"kernel": "kc_expand + kc_expand_runs + kc_expand_fb_run", "bound": "hbm",
+                        "algorithmic_bytes": int(exp_cols * 8 * n), "sum_launch_ms": round(exp_ms, 3),
+                        "achieved": round(exp_cols * 8 * n / exp_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(exp_cols * 8 * n / exp_ms / 1e6 / HBM_PEAK_GBS, 4)}}
+    prog.close()
+    return res
 
 
 def cpu_baseline(p2e, seed):
@@ -141,6 +188,7 @@ def main():
                          "(asynchronous C ABI), so the scalar phase and first chain pieces of the next batch "
                          "run under the expansion of the current one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-p256", action="store_true", help="skip the P-256 verifier leg (SURVEY 8(f) rank 4 on the driver's line)")
     args = ap.parse_args()
 
     import numpy as np
@@ -400,6 +448,13 @@ def main():
                 line["value_with_allgather"] = round(total / (elapsed / args.steps + gather["ms"] / 1e3), 1)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["cpu_baseline_optimised"] = cpu_baseline(p2e, seed=4)
+        if world == 1 and not args.no_p256 and not args.compact and args.batch_log2 == 16:
+            try:
+                cols_bufs.clear()
+                torch.cuda.empty_cache()
+                line["p256_verify"] = p256_leg(p2e, torch, ctx, dev, n)
+            except Exception as e:   # the headline line must survive this leg
+                line["p256_verify"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
