@@ -73,6 +73,7 @@ def usable_cores(omp_max):
 
 def p256_leg(p2e, torch, ctx, dev, n):
     """verify_p256_message_circuit witnesses of n synthetic P-256 signatures through the curve-program entry point."""
+    import numpy as np
     b = p2e.synth_signatures_curve(p2e.CURVE_P256, seed=777, n=1)      # any multiple of G serves as the circuit's rand() point
     blind = (int.from_bytes(bytes(b[3][0]), "little"), int.from_bytes(bytes(b[4][0]), "little"))
     prog = p2e.CurveProgram(ctx, p2e.CP_VERIFY, p2e.CURVE_P256, blind)
