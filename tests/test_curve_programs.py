@@ -289,6 +289,31 @@ def test_kernel_bodies_edge_inputs(emu):
                 assert err[i] == 0 and np.array_equal(cols[:, i], np.asarray(ref, np.uint64)), (cv.name, kind, i)
 
 
+def test_degenerate_points_are_flagged_where_the_reference_panics(emu):
+    """the gadgets use the incomplete affine formulas: the caller's point equal to the circuit's blinding point (or its
+    negative) makes precompute_window add a point to itself / to its negative -> x2 - x1 = 0 -> the inverse generator
+    panics in the reference (gadgets/nonnative.rs:863); every such element carries P2E_ERR_INVERSE_OF_ZERO, its
+    neighbours in the batch are untouched"""
+    rng = R.SplitMix64(321)
+    arr = lambda vs: np.stack([np.frombuffer(int(v).to_bytes(32, "little"), np.uint8).copy() for v in vs])
+    for ci, cv in enumerate(CURVES):
+        blind = cv.mul(rng.below(cv.n), cv.g)
+        b = (arr([blind[0]])[0], arr([blind[1]])[0])
+        good = cv.mul(rng.below(cv.n), cv.g)
+        pts = [good, blind, cv.neg(blind), good]
+        ks = [rng.below(cv.n) for _ in pts]
+        for kind, f in ((1, R.windowed_mul_witness), (2, R.scalar_mul_witness)):
+            cols, err, valid, bad = emu.run(kind, ci, b, (arr([p[0] for p in pts]), arr([p[1] for p in pts]), arr(ks)))
+            for i, pt in enumerate(pts):
+                try:
+                    ref = f(cv, pt[0], pt[1], ks[i], blind)[0]
+                except R.RefPanic as e:
+                    assert e.code == R.ERR_INVERSE_OF_ZERO and err[i] & R.ERR_INVERSE_OF_ZERO, (cv.name, kind, i)
+                    continue
+                assert err[i] == 0 and np.array_equal(cols[:, i], np.asarray(ref, np.uint64)), (cv.name, kind, i)
+            assert err[0] == 0 and err[3] == 0 and (kind == 2 or (err[1] and err[2]))
+
+
 @pytest.mark.parametrize("name", PROGRAMS)
 def test_builder_wiring_equals_the_replayed_gadget_wiring(name, emu):
     """the C++ schedule builder's generator table and operand wiring (p2e_curve_program_describe / _wiring) against the
