@@ -525,6 +525,12 @@ struct p2e_ctx {
     // Below this batch size phases A and B are latency, not throughput: four lanes per signature walk the chains
     // (k_chains_quad) and every inversion batch is cut into 2^binv_split_log2 sub-ranges (k_batch_inv_split)
     size_t quad_max_n = 24576;
+    // Between the two plans (lane per signature, but fewer than one chain wave per SIMD) phase B is the serial resource:
+    // its kernels are latency-bound (half a wave per SIMD at 2^15) and queue on one stream from the first piece to the
+    // last, with every expansion waiting behind them.  Below this batch size the inversion batches of consecutive pieces
+    // alternate between two streams -- and are cut into 2^binv_mid_split_log2 sub-ranges each -- so that they overlap.
+    size_t binv_alt_max_n = 49152;
+    int binv_mid_split_log2 = 1;   // 2^15 per call: 7.03-7.08 ms on one stream, 6.76-6.83 alternating, 6.68-6.72 alternating and split in two
     int binv_split_log2 = 2;
     // small-batch plan: dynamic LDS bytes requested by the expansion kernels (they do not use it): caps how many of
     // their workgroups share a CU, so that the register file keeps room for the chain waves queued behind them
@@ -693,6 +699,11 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     if (const char* env = getenv("P2E_FB_RUN")) c->fb_run = atoi(env) != 0;
     if (const char* env = getenv("P2E_RUNS_MIN_N")) c->runs_min_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_QUAD_MAX_N")) c->quad_max_n = (size_t)strtoull(env, nullptr, 10);
+    if (const char* env = getenv("P2E_BINV_ALT_MAX_N")) c->binv_alt_max_n = (size_t)strtoull(env, nullptr, 10);
+    if (const char* env = getenv("P2E_BINV_MID_SPLIT_LOG2")) {
+        int v = atoi(env);
+        if (v >= 0 && v <= 3) c->binv_mid_split_log2 = v;
+    }
     if (const char* env = getenv("P2E_EXPAND_LDS_SMALL")) c->expand_lds_small = (unsigned)strtoul(env, nullptr, 10);
     if (const char* env = getenv("P2E_EXPAND_LDS")) c->expand_lds = (unsigned)strtoul(env, nullptr, 10);
     {   // never ask for more dynamic LDS than a workgroup may have on this device (160 KB on gfx950)
@@ -1364,9 +1375,10 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     c->n_seg = ns;
 
     const unsigned gx4 = (unsigned)((4 * n + BS - 1) / BS);
+    const bool alt_b = quad || n < c->binv_alt_max_n;   // phase B of consecutive pieces on two streams
     auto launch_binv = [&](hipStream_t st, int lo, int hi, int have_prefix, bool last_piece = false) {
-        const int sl = last_piece ? c->binv_split_log2_last : c->binv_split_log2;
-        if (quad && sl > 0)
+        const int sl = !quad ? (alt_b ? c->binv_mid_split_log2 : 0) : last_piece ? c->binv_split_log2_last : c->binv_split_log2;
+        if ((quad || alt_b) && sl > 0)
             hipLaunchKernelGGL(k_batch_inv_split, dim3((unsigned)(((n << sl) + BS - 1) / BS)), dim3(BS), 0, st, G, B, lo, hi,
                                have_prefix, sl);
         else
@@ -1379,7 +1391,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->st_msm, c->ev_fork, 0));
     HIP_TRY(hipStreamWaitEvent(c->st_fixed, c->ev_fork, 0));
-    if (quad) HIP_TRY(hipStreamWaitEvent(c->st_binv, c->ev_fork, 0));
+    if (alt_b) HIP_TRY(hipStreamWaitEvent(c->st_binv, c->ev_fork, 0));
     // chains
     for (int k = 0; k < ns; k++) {
         Seg& sg = segs[k];
@@ -1444,7 +1456,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         // with C.  The fixed-base chain's stream is idle after its first ~1 ms, so phase B lives there.
         // (small-batch plan: phase B of consecutive pieces alternates between two streams, so that an inversion batch
         // does not queue behind the previous one -- there the chains are no slower than phase B)
-        hipStream_t st_b = (quad && (q & 1)) ? c->st_binv : c->st_fixed;
+        hipStream_t st_b = (alt_b && (q & 1)) ? c->st_binv : c->st_fixed;
         if (k != first_msm) {
             HIP_TRY(hipStreamWaitEvent(st_b, c->ev_piece[k], 0));
             launch_binv(st_b, sg.lo, sg.hi, 1, k == ns - 1);

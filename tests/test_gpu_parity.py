@@ -397,6 +397,36 @@ def test_api_misuse_returns_status_not_crash():
     assert L.p2e_aux_witness_batch(*ok_args()) >= 0                   # an all-zero matrix is a valid (if meaningless) input
 
 
+def test_mid_size_batch_between_the_two_plans():
+    """24 576 < n < 49 152 (the N = 2 point of the strong-scaled shape): lane-per-signature chains, but the inversion
+    batches of consecutive pieces alternate between two streams and are cut into two sub-ranges each (k_batch_inv_split
+    behind k_chains).  33 000 + 77 signatures (ragged), both programs: flags, and 64 sampled signatures on every column."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    n = 33000 + 77
+    sigs = p2e.synth_signatures(seed=15, n=n)
+    sigs[2][1234, 0] ^= 1                                       # one tampered s
+    ctx = p2e.Context(device=0)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    cols, err, valid, bad = ctx.ecdsa_verify_witness_batch(*dev)
+    torch.cuda.synchronize()
+    v = valid.cpu().numpy()
+    assert bad == 0 and int(err.sum()) == 0 and v.sum() == n - 1 and v[1234] == 0
+    sample = np.unique(np.concatenate([np.linspace(0, n - 1, 62).astype(np.int64), [1234, n - 1]]))
+    want, werr, wflags = oracle_c.verify_witness(*[a[sample] for a in sigs])
+    got = cols[:, torch.from_numpy(sample).cuda()].cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want) and np.array_equal(v[sample], wflags)
+    rng = R.SplitMix64(4242)
+    k = oracle_c.pack256([rng.below(R.N) for _ in range(len(sample))])
+    kk = np.zeros((n, 32), np.uint8)
+    kk[:] = k[0]
+    kk[sample] = k
+    gcols, gerr, _, gbad = ctx.glv_mul_witness_batch(dev[3], dev[4], torch.from_numpy(kk).cuda())
+    torch.cuda.synchronize()
+    want, _, _ = oracle_c.glv_mul_witness(sigs[3][sample], sigs[4][sample], k)
+    assert gbad == 0 and np.array_equal(gcols[:, torch.from_numpy(sample).cuda()].cpu().numpy().view(np.uint64), want)
+
+
 def test_full_size_batch_properties():
     """BASELINE metric config: 2^16 verifies on one GPU.  Size-independent properties:
     every synthetic signature verifies (the r == x connect constraint at the END of the 3.5k-op chain),
