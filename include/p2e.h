@@ -355,6 +355,9 @@ long p2e_curve_program_num_gate_cols(const p2e_curve_program *prog);
 long p2e_curve_program_num_ux_cols(const p2e_curve_program *prog);
 long p2e_curve_program_ux_describe(const p2e_curve_program *prog, p2e_ux_desc *out, size_t cap);
 /* inputs as for the program's fill (multiplication programs: the scalar in msg32, r32 = s32 = NULL) */
+/* the wire map of p2e_wire_map_create for this program's matrices (then p2e_assemble_wires / p2e_wire_map_destroy) */
+int p2e_curve_program_wire_map_create(p2e_ctx *ctx, const p2e_curve_program *prog, const p2e_wire_map_entry *entries,
+                                      size_t count, uint32_t num_wires, uint32_t degree, p2e_wire_map **out);
 long p2e_curve_program_aux_witness_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *msg32, const uint8_t *r32,
                                          const uint8_t *s32, const uint8_t *pkx32, const uint8_t *pky32, const uint64_t *cols,
                                          size_t ld, uint64_t *aux, size_t ld_aux, size_t n, uint8_t *err);

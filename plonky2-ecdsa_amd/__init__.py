@@ -67,6 +67,7 @@ EXPORTS = (
     "p2e_curve_program_const", "p2e_curve_mul_witness_batch", "p2e_p256_verify_witness_batch", "p2e_synth_signatures_curve",
     "p2e_curve_program_num_gate_cols", "p2e_curve_program_num_ux_cols", "p2e_curve_program_ux_describe",
     "p2e_curve_program_aux_witness_batch", "p2e_curve_program_gate_internal_batch", "p2e_curve_program_ux_witness_batch",
+    "p2e_curve_program_wire_map_create",
 )
 
 
@@ -414,6 +415,19 @@ class CurveProgram:
                                                                    _ptr(cols), C.c_size_t(ld), _ptr(aux), C.c_size_t(_ld(aux)), _ptr(ux),
                                                                    C.c_int(1 if u32 else 0), C.c_size_t(_ld(ux)), C.c_size_t(n), _ptr(err)))
         return ux, err, bad
+
+    def wire_map(self, src, dst, num_wires, degree):
+        """a column -> (wire, row) map over THIS program's four matrices, for Context.assemble_wires"""
+        ctx = self._ctx
+        src, dst = np.ascontiguousarray(src, np.uint32), np.ascontiguousarray(dst, np.uint32)
+        ent = np.empty((len(src), 2), dtype=np.uint32)
+        ent[:, 0], ent[:, 1] = src, dst
+        h = C.c_void_p()
+        rc = ctx._L.p2e_curve_program_wire_map_create(ctx._h, self._h, _ptr(ent), C.c_size_t(len(src)), C.c_uint32(num_wires),
+                                                      C.c_uint32(degree), C.byref(h))
+        if rc != 0:
+            raise P2EError(f"p2e_curve_program_wire_map_create failed ({rc}): {ctx._L.p2e_last_error().decode()}")
+        return _WireMap(ctx, h, -1, num_wires, degree, len(src))
 
     def verify_witness_batch(self, msg, r, s, pkx, pky, cols=None, err=None, valid=None, ld=None):
         """verify_p256_message_circuit: (115557, n) columns."""

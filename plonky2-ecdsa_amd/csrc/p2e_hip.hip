@@ -1680,19 +1680,17 @@ extern "C" long p2e_aux_witness_compact_batch(p2e_ctx* c, int program, const uin
 }
 
 struct p2e_wire_map {
-    int program = 0;
+    u32 limit[4] = {0, 0, 0, 0};   // column counts of the four source matrices (witness, aux, ux, gate) of the map's program
     u32* d_src = nullptr;
     u32* d_dst = nullptr;
     size_t count = 0;
     u32 num_wires = 0, degree = 0;
     bool uses[4] = {false, false, false, false};
 };
-extern "C" int p2e_wire_map_create(p2e_ctx* c, int program, const p2e_wire_map_entry* entries, size_t count, uint32_t num_wires,
-                                   uint32_t degree, p2e_wire_map** out) {
-    if (!c || !out || program < 0 || program > 1 || (!entries && count) || !num_wires || !degree) return P2E_E_INVALID;
-    const DeviceProgram& HP = host_program(program);
+static int make_wire_map(p2e_ctx* c, const u32 limit[4], const p2e_wire_map_entry* entries, size_t count, uint32_t num_wires,
+                         uint32_t degree, p2e_wire_map** out) {
+    if (!c || !out || (!entries && count) || !num_wires || !degree) return P2E_E_INVALID;
     const u64 cells = (u64)num_wires * degree;
-    const u32 limit[4] = {(u32)HP.prog.num_cols, HP.aux_tab.num_aux_cols, HP.num_ux_cols, HP.num_gate_cols};
     std::vector<p2e_wire_map_entry> v(entries, entries + count);
     std::stable_sort(v.begin(), v.end(), [](const p2e_wire_map_entry& a, const p2e_wire_map_entry& b) { return a.dst < b.dst; });
     auto m = new p2e_wire_map();
@@ -1713,7 +1711,7 @@ extern "C" int p2e_wire_map_create(p2e_ctx* c, int program, const p2e_wire_map_e
         dst[k] = v[k].dst;
     }
     DeviceGuard guard(c->device);
-    m->program = program;
+    for (int k = 0; k < 4; k++) m->limit[k] = limit[k];
     m->count = count;
     m->num_wires = num_wires;
     m->degree = degree;
@@ -1729,6 +1727,13 @@ extern "C" int p2e_wire_map_create(p2e_ctx* c, int program, const p2e_wire_map_e
     }
     *out = m;
     return 0;
+}
+extern "C" int p2e_wire_map_create(p2e_ctx* c, int program, const p2e_wire_map_entry* entries, size_t count, uint32_t num_wires,
+                                   uint32_t degree, p2e_wire_map** out) {
+    if (program < 0 || program > 1) return P2E_E_INVALID;
+    const DeviceProgram& HP = host_program(program);
+    const u32 limit[4] = {(u32)HP.prog.num_cols, HP.aux_tab.num_aux_cols, HP.num_ux_cols, HP.num_gate_cols};
+    return make_wire_map(c, limit, entries, count, num_wires, degree, out);
 }
 extern "C" void p2e_wire_map_destroy(p2e_ctx* c, p2e_wire_map* m) {
     if (!m) return;
@@ -1749,12 +1754,11 @@ extern "C" long p2e_assemble_wires(p2e_ctx* c, const p2e_wire_map* m, const uint
         return P2E_E_INVALID;
     }
     if (n == 0 || m->count == 0) return 0;
-    const DeviceProgram& DP = c->progs[m->program];
     Staged S(c);
-    if (cols) cols = S.in(cols, (size_t)DP.prog.num_cols * ld * 8);
-    if (aux) aux = S.in(aux, (size_t)DP.aux_tab.num_aux_cols * ld_aux * 8);
-    if (ux) ux = S.in((const char*)ux, (size_t)DP.num_ux_cols * ld_ux * (ux_u32 ? 4 : 8));
-    if (gate) gate = S.in(gate, (size_t)DP.num_gate_cols * ld_gate * 8);
+    if (cols) cols = S.in(cols, (size_t)m->limit[0] * ld * 8);
+    if (aux) aux = S.in(aux, (size_t)m->limit[1] * ld_aux * 8);
+    if (ux) ux = S.in((const char*)ux, (size_t)m->limit[2] * ld_ux * (ux_u32 ? 4 : 8));
+    if (gate) gate = S.in(gate, (size_t)m->limit[3] * ld_gate * 8);
     uint64_t* const host_wires = wires;
     void* d_stage = nullptr;
     if (S.host) {   // in-out buffer: positions no entry names keep the caller's values

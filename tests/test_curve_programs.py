@@ -502,6 +502,42 @@ def test_gpu_other_targets_of_the_circuits(name, gpu, emu):
 
 
 @pytest.mark.gpu
+def test_gpu_wire_assembly_of_a_curve_program(gpu):
+    """SURVEY 8(f) rank 3 for the P-256 verifier: its four matrices scattered into one wire matrix per signature through
+    a random host-supplied map (p2e_curve_program_wire_map_create + p2e_assemble_wires), against numpy"""
+    p2e, torch, ctx = gpu
+    cv = R.P256
+    prog = p2e.CurveProgram(ctx, p2e.CP_VERIFY, p2e.CURVE_P256, cv.mul(31337, cv.g))
+    n = 80
+    dev = [torch.from_numpy(a).cuda() for a in p2e.synth_signatures_curve(p2e.CURVE_P256, seed=8, n=n)]
+    cols, _, valid, bad = prog.verify_witness_batch(*dev)
+    aux, _, _ = prog.aux_witness_batch(dev, cols)
+    ux, _, _ = prog.ux_witness_batch(dev, cols, aux, u32=True)
+    gate = prog.gate_internal_batch(aux)
+    torch.cuda.synchronize()
+    assert bad == 0 and int(valid.sum()) == n
+    mats = [cols.cpu().numpy().view(np.uint64), aux.cpu().numpy().view(np.uint64), ux.cpu().numpy().view(np.uint32), gate.cpu().numpy().view(np.uint64)]
+    limits = [prog.num_cols, prog.num_aux_cols, prog.num_ux_cols, prog.num_gate_cols]
+    rng = np.random.default_rng(9)
+    cnt, cells = 60_003, 1 << 17
+    kinds = rng.integers(0, 4, cnt).astype(np.uint32)
+    colsel = np.array([rng.integers(0, limits[k]) for k in kinds], dtype=np.uint32)
+    src = (kinds << 30) | colsel
+    dst = rng.permutation(cells)[:cnt].astype(np.uint32)
+    wm = prog.wire_map(src, dst, 128, cells // 128)
+    wires = ctx.assemble_wires(wm, cols, aux, ux, gate)
+    torch.cuda.synchronize()
+    want = np.zeros((n, cells), np.uint64)
+    for k in range(4):
+        sel = kinds == k
+        want[:, dst[sel]] = mats[k][colsel[sel]].T
+    assert np.array_equal(wires.cpu().numpy().view(np.uint64), want)
+    with pytest.raises(p2e.P2EError):                            # a source column beyond this program's witness matrix
+        prog.wire_map(np.array([prog.num_cols], np.uint32), np.array([0], np.uint32), 4, 4)
+    prog.close()
+
+
+@pytest.mark.gpu
 def test_gpu_p256_verify_batch_properties(gpu):
     """4 096 + 77 P-256 verifies: every valid signature verifies, every limb column is a 29-bit limb, tampering with
     any of the five inputs clears `valid`, sampled signatures pass the constraint replay"""
