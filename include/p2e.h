@@ -375,6 +375,11 @@ long p2e_curve_mul_witness_batch(p2e_ctx *ctx, const p2e_curve_program *prog, co
 long p2e_p256_verify_witness_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *msg32, const uint8_t *r32,
                                    const uint8_t *s32, const uint8_t *pkx32, const uint8_t *pky32, uint64_t *cols, size_t n,
                                    size_t ld, uint8_t *err, uint8_t *valid);
+/* the P-256 verifier's verdict alone (the counterpart of p2e_ecdsa_verify_batch; native: curve/ecdsa.rs:42-62
+ * verify_message with C = P256, with exactly the circuit's verdict): no witness, 2 bytes per signature */
+long p2e_p256_verify_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *msg32, const uint8_t *r32,
+                           const uint8_t *s32, const uint8_t *pkx32, const uint8_t *pky32, size_t n, uint8_t *err,
+                           uint8_t *valid);
 /* synthetic valid signatures on a curve (host only; P2E_CURVE_*), same stream layout as p2e_synth_signatures */
 int p2e_synth_signatures_curve(int curve, uint64_t seed, size_t first, size_t n, uint8_t *msg32, uint8_t *r32, uint8_t *s32,
                                uint8_t *pkx32, uint8_t *pky32);

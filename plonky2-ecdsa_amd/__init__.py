@@ -67,7 +67,7 @@ EXPORTS = (
     "p2e_curve_program_const", "p2e_curve_mul_witness_batch", "p2e_p256_verify_witness_batch", "p2e_synth_signatures_curve",
     "p2e_curve_program_num_gate_cols", "p2e_curve_program_num_ux_cols", "p2e_curve_program_ux_describe",
     "p2e_curve_program_aux_witness_batch", "p2e_curve_program_gate_internal_batch", "p2e_curve_program_ux_witness_batch",
-    "p2e_curve_program_wire_map_create",
+    "p2e_curve_program_wire_map_create", "p2e_p256_verify_batch",
 )
 
 
@@ -415,6 +415,16 @@ class CurveProgram:
                                                                    _ptr(cols), C.c_size_t(ld), _ptr(aux), C.c_size_t(_ld(aux)), _ptr(ux),
                                                                    C.c_int(1 if u32 else 0), C.c_size_t(_ld(ux)), C.c_size_t(n), _ptr(err)))
         return ux, err, bad
+
+    def verify_batch(self, msg, r, s, pkx, pky, err=None, valid=None):
+        """the verifier circuit's verdict alone (no witness): (err, valid, flagged count)"""
+        ctx = self._ctx
+        n = ctx._shape(msg)[0]
+        err = err if err is not None else ctx._vec(n, np.uint8)
+        valid = valid if valid is not None else ctx._vec(n, np.uint8)
+        bad = ctx._check(ctx._L.p2e_p256_verify_batch(ctx._h, self._h, _ptr(msg), _ptr(r), _ptr(s), _ptr(pkx), _ptr(pky), C.c_size_t(n),
+                                                      _ptr(err), _ptr(valid)))
+        return err, valid, bad
 
     def wire_map(self, src, dst, num_wires, degree):
         """a column -> (wire, row) map over THIS program's four matrices, for Context.assemble_wires"""

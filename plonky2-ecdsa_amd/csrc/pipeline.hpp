@@ -420,11 +420,16 @@ P2E_HD void body_chain_rows(const Program& G, const Buffers& B, size_t i, int lo
 
 // The connect r == x of gadgets/ecdsa.rs:48-52 on the final add's JACOBIAN result (p2e_ecdsa_verify_batch: verdict
 // only, no batch inversion): x = X / Z^2 is canonical, so x == r  <=>  r < p and X == r * Z^2.
-P2E_HD void body_verify_check(const Program& G, const Buffers& B, size_t i) {
-    const size_t o = (size_t)(G.chain_end[2] - 1) * B.n + i;
+template <class CV = Secp256k1>
+P2E_HD void body_verify_check(const Program& G, const Buffers& B, size_t i, int last_op) {
+    typedef typename CV::Fp F;
+    const size_t o = (size_t)last_op * B.n + i;
     const U256 r = load_packed(B.r, i), X = B.PX[o], Z = B.PZ[o];
-    const bool r_lt_p = !geq_mod<ModP>(r.w);
-    if (!(r_lt_p && !u256_is_zero(Z) && u256_eq(fp_mul(r, fp_sqr(Z)), X))) B.valid[i] = 0;
+    const bool r_lt_p = !geq_mod<F>(r.w);
+    if (!(r_lt_p && !u256_is_zero(Z) && u256_eq(fe_mul<F>(r, fe_sqr<F>(Z)), X))) B.valid[i] = 0;
+}
+P2E_HD void body_verify_check(const Program& G, const Buffers& B, size_t i) {
+    body_verify_check<Secp256k1>(G, B, i, G.chain_end[2] - 1);
 }
 
 // ---- phase B: Montgomery batch inversion of Z over ops [t0, t1) of one signature ------------------------

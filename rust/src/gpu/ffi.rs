@@ -170,6 +170,8 @@ extern "C" {
         ux: *mut c_void, ux_u32: i32, ld_ux: usize, n: usize, err: *mut u8) -> i64;
     pub fn p2e_curve_program_wire_map_create(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, entries: *const P2eWireMapEntry,
         count: usize, num_wires: u32, degree: u32, out: *mut *mut P2eWireMap) -> i32;
+    pub fn p2e_p256_verify_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, msg32: *const u8, r32: *const u8, s32: *const u8,
+        pkx32: *const u8, pky32: *const u8, n: usize, err: *mut u8, valid: *mut u8) -> i64;
     pub fn p2e_curve_mul_witness_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, px32: *const u8, py32: *const u8,
         k32: *const u8, cols: *mut u64, n: usize, ld: usize, err: *mut u8, valid: *mut u8) -> i64;
     pub fn p2e_p256_verify_witness_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, msg32: *const u8, r32: *const u8,

@@ -706,6 +706,48 @@ long emu_p256_reduce_selfcheck(long count, uint64_t seed) {
     }
     return bad;
 }
+// verdict only of the P-256 verifier program (p2e_p256_verify_batch): scalar phase without emission, the chains in
+// Jacobian coordinates (table left Jacobian), r == x on the Jacobian result of the final add
+long emu_p256_verify_only(const uint8_t* blind_x, const uint8_t* blind_y, const uint8_t* msg, const uint8_t* r, const uint8_t* s,
+                          const uint8_t* pkx, const uint8_t* pky, size_t n, uint8_t* err, uint8_t* valid) {
+    Aff blind;
+    memcpy(blind.x.w, blind_x, 32);
+    memcpy(blind.y.w, blind_y, 32);
+    host::CurveProgramHost H;
+    if (!host::make_curve_program(H, CP_VERIFY, 1, blind)) return -1;
+    const host::ScheduleBuilder& sb = H.sb;
+    const Program& G = sb.prog;
+    const size_t rows = (size_t)(G.cp_rows > MSM_DIGITS ? G.cp_rows : MSM_DIGITS);
+    std::vector<U256> PX((size_t)G.num_slots * n), PY((size_t)G.num_slots * n), PZ((size_t)G.num_slots * n),
+        PW((size_t)G.num_ops * n), PREF((size_t)G.num_ops * n), AX((size_t)G.num_slots * n), AY((size_t)G.num_slots * n);
+    std::vector<uint8_t> dig4((size_t)FB_WINDOWS * n), dig2(rows * n), valid8(n);
+    std::vector<uint16_t> dyn((size_t)G.num_cadd * n + 1), src((size_t)G.num_ops * 2 * n), msrc(rows * n);
+    std::vector<u32> err32(n);
+    Buffers B{};
+    B.msg = msg; B.r = r; B.s = s; B.pkx = pkx; B.pky = pky;
+    B.n = n;
+    B.err = err32.data(); B.valid = valid8.data();
+    B.PX = PX.data(); B.PY = PY.data(); B.PZ = PZ.data(); B.PW = PW.data(); B.PREF = PREF.data();
+    B.AX = AX.data(); B.AY = AY.data();
+    B.dig4 = dig4.data(); B.dig2 = dig2.data(); B.dyn = dyn.data(); B.src = src.data(); B.msrc = msrc.data();
+    B.cpts = sb.gpts.data(); B.fbtab = sb.gfbtab.data(); B.ops = sb.ops.data();
+    const int fb_end = G.fb_begin + G.fb_windows + 1;
+#pragma omp parallel for
+    for (long long i = 0; i < (long long)n; i++) {
+        body_cscalar<P256, NullEmit>(G, B, (size_t)i);
+        body_chain_range<P256, true>(G, B, (size_t)i, G.fb_begin, fb_end, false, false);
+        body_chain_range<P256, true>(G, B, (size_t)i, fb_end, G.num_ops - 1, false, false);
+        body_chain_range<P256, true>(G, B, (size_t)i, G.num_ops - 1, G.num_ops, false, false);
+        body_verify_check<P256>(G, B, (size_t)i, G.num_ops - 1);
+    }
+    long bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        err[i] = (uint8_t)err32[i];
+        valid[i] = err32[i] ? 0 : valid8[i];
+        bad += err32[i] != 0;
+    }
+    return bad;
+}
 int emu_synth_signatures_curve(int curve, uint64_t seed, size_t first, size_t n, uint8_t* msg32, uint8_t* r32, uint8_t* s32,
                                uint8_t* pkx32, uint8_t* pky32) {
 #pragma omp parallel for

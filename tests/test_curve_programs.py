@@ -314,6 +314,41 @@ def test_degenerate_points_are_flagged_where_the_reference_panics(emu):
             assert err[0] == 0 and err[3] == 0 and (kind == 2 or (err[1] and err[2]))
 
 
+def _tampered_p256_batch(n, seed):
+    """valid signatures with every kind of defect mixed in: tampered msg / r / s / pk.x, r >= p, s = 0 (inverse of zero)"""
+    import plonky2_ecdsa_amd as p2e  # host-side synthesis only (no GPU)
+    cv = R.P256
+    sig = [np.ascontiguousarray(a) for a in _synth_p256(n, seed)]
+    sig[0][3, 5] ^= 1
+    sig[1][4, 0] ^= 2
+    sig[2][5, 31] ^= 0x40
+    sig[3][6, 1] ^= 1                       # pk off the curve: curve_assert_valid's connect fails
+    sig[1][7] = np.frombuffer(((1 << 256) - 1).to_bytes(32, "little"), np.uint8)   # r >= p: can never equal x
+    sig[2][8] = 0                           # s = 0: the reference panics in inverse()
+    return sig
+
+
+def _synth_p256(n, seed):
+    lib = C.CDLL(os.path.join(ROOT, "tests", "emu", "libp2e_emu.so"))
+    out = [np.zeros((n, 32), np.uint8) for _ in range(5)]
+    assert lib.emu_synth_signatures_curve(1, C.c_uint64(seed), C.c_size_t(0), C.c_size_t(n), *[a.ctypes.data_as(C.c_void_p) for a in out]) == 0
+    return out
+
+
+def test_p256_verdict_only_equals_the_full_fill(emu):
+    """p2e_p256_verify_batch (no witness): same valid / err per signature as the full fill of the same inputs"""
+    cv = R.P256
+    blind_i = cv.mul(424242, cv.g)
+    blind = (np.frombuffer(blind_i[0].to_bytes(32, "little"), np.uint8).copy(), np.frombuffer(blind_i[1].to_bytes(32, "little"), np.uint8).copy())
+    sig = _tampered_p256_batch(12, 6)
+    _, err, valid, bad = emu.run(3, 1, blind, sig)
+    emu.L.emu_p256_verify_only.restype = C.c_long
+    err2, valid2 = np.zeros(12, np.uint8), np.zeros(12, np.uint8)
+    bad2 = emu.L.emu_p256_verify_only(emu._p(blind[0]), emu._p(blind[1]), *[emu._p(a) for a in sig], C.c_size_t(12), emu._p(err2), emu._p(valid2))
+    assert bad == bad2 and np.array_equal(err != 0, err2 != 0) and np.array_equal(valid, valid2)
+    assert list(valid) == [1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1, 1] and err[8] & R.ERR_INVERSE_OF_ZERO
+
+
 @pytest.mark.parametrize("name", PROGRAMS)
 def test_builder_wiring_equals_the_replayed_gadget_wiring(name, emu):
     """the C++ schedule builder's generator table and operand wiring (p2e_curve_program_describe / _wiring) against the
@@ -534,6 +569,24 @@ def test_gpu_wire_assembly_of_a_curve_program(gpu):
     assert np.array_equal(wires.cpu().numpy().view(np.uint64), want)
     with pytest.raises(p2e.P2EError):                            # a source column beyond this program's witness matrix
         prog.wire_map(np.array([prog.num_cols], np.uint32), np.array([0], np.uint32), 4, 4)
+    prog.close()
+
+
+@pytest.mark.gpu
+def test_gpu_p256_verdict_only(gpu):
+    """the pre-filter (no witness) against the full fill on a batch with every kind of defect, ragged size"""
+    p2e, torch, ctx = gpu
+    cv = R.P256
+    prog = p2e.CurveProgram(ctx, p2e.CP_VERIFY, p2e.CURVE_P256, cv.mul(424242, cv.g))
+    n = 700
+    sig = _tampered_p256_batch(n, 6)
+    dev = [torch.from_numpy(a).cuda() for a in sig]
+    _, err, valid, bad = prog.verify_witness_batch(*dev)
+    err2, valid2, bad2 = prog.verify_batch(*dev)
+    torch.cuda.synchronize()
+    assert bad == bad2 == 1
+    assert np.array_equal(err.cpu().numpy() != 0, err2.cpu().numpy() != 0) and np.array_equal(valid.cpu().numpy(), valid2.cpu().numpy())
+    assert int(valid2.sum()) == n - 6
     prog.close()
 
 
