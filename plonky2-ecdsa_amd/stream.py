@@ -17,7 +17,7 @@ import time
 
 import numpy as np
 
-from . import (PROGRAM_VERIFY, VERIFY_AUX_COLS, VERIFY_COLS, Context, P2EError,  # noqa: F401  (package namespace)
+from . import (PROGRAM_VERIFY, VERIFY_AUX_COLS, VERIFY_COLS, Context, CurveProgram, P2EError,  # noqa: F401  (package namespace)
                compact_layout)
 
 
@@ -33,18 +33,25 @@ class Chunk:
 class HostStreamer:
     """container: "u64" (cols: (82615, n) int64 host tensor, column-major over the chunk), "rows" (rows: (n, 82615),
     one contiguous witness per signature, transposed on the GPU first) or "compact" (narrow (num_narrow, n) int32 +
-    wide (num_wide, n) int64)."""
+    wide (num_wide, n) int64).
 
-    def __init__(self, device: int = 0, chunk: int = 8192, container: str = "u64"):
+    curve_program = (kind, curve, blind): stream a curve program's fill instead (the P-256 verifier,
+    or a stand-alone scalar multiplication whose inputs are (px, py, k)); containers "u64" and "rows"."""
+
+    def __init__(self, device: int = 0, chunk: int = 8192, container: str = "u64", curve_program=None):
         import torch
         if container not in ("u64", "rows", "compact"):
             raise P2EError("container must be u64, rows or compact")
+        if curve_program is not None and container == "compact":
+            raise P2EError("curve programs write the u64 matrix only")
         self.torch = torch
         self.device, self.chunk, self.container = device, int(chunk), container
         dev = f"cuda:{device}"
         self.compute = torch.cuda.Stream(device=dev)
         self.copy = torch.cuda.Stream(device=dev)
         self.ctx = Context(device=device, stream=self.compute.cuda_stream, asynchronous=True)
+        self.prog = CurveProgram(self.ctx, *curve_program) if curve_program is not None else None
+        self.ncols = self.prog.num_cols if self.prog is not None else VERIFY_COLS
         # n + 16: a power-of-two column stride camps on the same HBM channels (see Context.ecdsa_verify_witness_batch)
         self.ld = ld = self.chunk + 16
         two = range(2)
@@ -56,14 +63,15 @@ class HostStreamer:
             self.h_wid = [torch.empty((self.nw, ld), dtype=torch.int64, pin_memory=True) for _ in two]
             self.bytes_per_chunk = (self.nn * 4 + self.nw * 8) * ld
         else:
-            self.d_cols = [torch.empty((VERIFY_COLS, ld), dtype=torch.int64, device=dev) for _ in two]
+            nc = self.ncols
+            self.d_cols = [torch.empty((nc, ld), dtype=torch.int64, device=dev) for _ in two]
             if container == "rows":
-                self.d_rows = [torch.empty((self.chunk, VERIFY_COLS), dtype=torch.int64, device=dev) for _ in two]
-                self.h_rows = [torch.empty((self.chunk, VERIFY_COLS), dtype=torch.int64, pin_memory=True) for _ in two]
-                self.bytes_per_chunk = self.chunk * VERIFY_COLS * 8
+                self.d_rows = [torch.empty((self.chunk, nc), dtype=torch.int64, device=dev) for _ in two]
+                self.h_rows = [torch.empty((self.chunk, nc), dtype=torch.int64, pin_memory=True) for _ in two]
+                self.bytes_per_chunk = self.chunk * nc * 8
             else:
-                self.h_cols = [torch.empty((VERIFY_COLS, ld), dtype=torch.int64, pin_memory=True) for _ in two]
-                self.bytes_per_chunk = VERIFY_COLS * ld * 8
+                self.h_cols = [torch.empty((nc, ld), dtype=torch.int64, pin_memory=True) for _ in two]
+                self.bytes_per_chunk = nc * ld * 8
         self.d_err = [torch.empty(self.chunk, dtype=torch.uint8, device=dev) for _ in two]
         self.d_valid = [torch.empty(self.chunk, dtype=torch.uint8, device=dev) for _ in two]
         self.h_err = [torch.empty(self.chunk, dtype=torch.uint8, pin_memory=True) for _ in two]
@@ -79,7 +87,12 @@ class HostStreamer:
                 self.ctx.ecdsa_verify_witness_compact_batch(*sl, narrow=self.d_nar[b], wide=self.d_wid[b], err=self.d_err[b],
                                                             valid=self.d_valid[b], ld_narrow=self.ld, ld_wide=self.ld)
             else:
-                self.ctx.ecdsa_verify_witness_batch(*sl, cols=self.d_cols[b], err=self.d_err[b], valid=self.d_valid[b], ld=self.ld)
+                if self.prog is None:
+                    self.ctx.ecdsa_verify_witness_batch(*sl, cols=self.d_cols[b], err=self.d_err[b], valid=self.d_valid[b], ld=self.ld)
+                elif len(sl) == 5:
+                    self.prog.verify_witness_batch(*sl, cols=self.d_cols[b], err=self.d_err[b], valid=self.d_valid[b], ld=self.ld)
+                else:
+                    self.prog.mul_witness_batch(*sl, cols=self.d_cols[b], err=self.d_err[b], valid=self.d_valid[b], ld=self.ld)
                 if self.container == "rows":
                     self.ctx.columns_to_rows(self.d_cols[b], n=n, ld=self.ld, rows=self.d_rows[b])
             self.done_compute[b].record(self.compute)
@@ -109,7 +122,7 @@ class HostStreamer:
 
     def run(self, dev_inputs, consumer=None):
         """dev_inputs: the five (total, 32) uint8 DEVICE tensors (msg, r, s, pk.x, pk.y) of the whole stream (160 B per
-        signature: they stay resident).  consumer(chunk) is called once per chunk, in order, on the host copy.
+        signature: they stay resident); (px, py, k) for a multiplication program.  consumer(chunk) is called once per chunk, in order, on the host copy.
         Returns {"seconds", "fills_per_s_pcie_inclusive", "d2h_GBps", "bytes_d2h", "flagged", "valid", "chunks"}."""
         torch = self.torch
         total = int(dev_inputs[0].shape[0])

@@ -591,6 +591,36 @@ def test_gpu_p256_verdict_only(gpu):
 
 
 @pytest.mark.gpu
+def test_gpu_streamed_chunks_of_the_p256_verifier(emu):
+    """the BASELINE config 5 shape for the P-256 verifier: 3 x 1 024 + 300 signatures streamed to pinned host memory in
+    double-buffered chunks (plonky2_ecdsa_amd.stream.HostStreamer with a curve program), EVERY chunk checked on the host
+    copy against the CPU-compiled kernel bodies, as columns and as per-signature rows"""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    from plonky2_ecdsa_amd.stream import HostStreamer
+    cv = R.P256
+    blind_i = cv.mul(777, cv.g)
+    blind = (np.frombuffer(blind_i[0].to_bytes(32, "little"), np.uint8).copy(), np.frombuffer(blind_i[1].to_bytes(32, "little"), np.uint8).copy())
+    total, chunk = 3 * 1024 + 300, 1024
+    sig = p2e.synth_signatures_curve(p2e.CURVE_P256, seed=21, n=total)
+    sig[0][2000, 9] ^= 4
+    want, werr, wvalid, _ = emu.run(p2e.CP_VERIFY, p2e.CURVE_P256, blind, sig)
+    dev = [torch.from_numpy(a).cuda() for a in sig]
+    for container in ("u64", "rows"):
+        hs = HostStreamer(device=0, chunk=chunk, container=container, curve_program=(p2e.CP_VERIFY, p2e.CURVE_P256, blind_i))
+        seen = []
+
+        def consumer(ch):
+            got = ch.cols.numpy().view(np.uint64) if container == "u64" else ch.rows.numpy().view(np.uint64).T
+            assert np.array_equal(got, want[:, ch.first:ch.first + ch.n]), (container, ch.index)
+            assert np.array_equal(ch.valid, wvalid[ch.first:ch.first + ch.n])
+            seen.append(ch.n)
+        res = hs.run(dev, consumer)
+        assert seen == [1024, 1024, 1024, 300] and res["flagged"] == 0 and res["valid"] == total - 1
+        hs.prog.close()
+
+
+@pytest.mark.gpu
 def test_gpu_p256_verify_batch_properties(gpu):
     """4 096 + 77 P-256 verifies: every valid signature verifies, every limb column is a 29-bit limb, tampering with
     any of the five inputs clears `valid`, sampled signatures pass the constraint replay"""
