@@ -376,6 +376,17 @@ def test_plain_c_client(tmp_path):
     assert "300 fills x 82615 columns, 0 flagged, 300 signatures verify" in r.stdout
 
 
+def test_plain_c_client_of_the_p256_verifier(tmp_path):
+    """examples/fill_p256.c: curve program create / fill / verdict-only pre-filter / describe from plain C"""
+    import subprocess
+    from test_host import _build_c_example
+    exe, env = _build_c_example(tmp_path, "fill_p256")
+    r = subprocess.run([exe, "300"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "300 P-256 fills x 115557 columns, 0 flagged, 299 signatures verify, pre-filter agrees on 300" in r.stdout
+    assert "4828 generators" in r.stdout
+
+
 def test_api_misuse_returns_status_not_crash():
     import plonky2_ecdsa_amd as p2e
     ctx = p2e.Context(device=0, host_pointers=True)

@@ -124,11 +124,11 @@ def test_compact_emitter_bodies_match_the_oracle(program):
     assert not aerr.any() and np.array_equal(aux32.astype(np.uint64), ora.aux(program, inputs)[1])
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="fill_batch"):
     import subprocess
-    exe = str(tmp_path / "fill_batch")
+    exe = str(tmp_path / name)
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "fill_batch.c"), "-L", os.path.join(ROOT, "plonky2-ecdsa_amd"),
+                           os.path.join(ROOT, "examples", name + ".c"), "-L", os.path.join(ROOT, "plonky2-ecdsa_amd"),
                            "-lp2e_hip", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "plonky2-ecdsa_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""),
                GPU_MAX_HW_QUEUES="8")
@@ -141,11 +141,13 @@ def test_plain_c_client_builds_against_the_header_and_fails_loudly_without_a_gpu
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c",
                            os.path.join(ROOT, "include", "p2e.h")])
     exe, env = _build_c_example(tmp_path)
+    exe2, _ = _build_c_example(tmp_path, "fill_p256")
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is visible: covered by the GPU suite")
-    r = subprocess.run([exe, "8"], env=env, capture_output=True, text=True)
-    assert r.returncode == 2 and "no CPU fallback" in r.stderr
+    for e in (exe, exe2):
+        r = subprocess.run([e, "8"], env=env, capture_output=True, text=True)
+        assert r.returncode == 2 and "no CPU fallback" in r.stderr
 
 
 def test_div_rem_bodies_random_shapes():
