@@ -465,6 +465,7 @@ struct DeviceProgram {
     Program prog;
     OpDesc* d_ops = nullptr;        // with the run marks of ctx->run_iters (F_NO_AFFINE)
     OpDesc* d_ops_plain = nullptr;  // without: every op expanded on its own (small batches)
+    OpDesc* d_ops_mid = nullptr;    // with the run marks of ctx->run_iters_mid (mid-size batches)
     std::vector<OpDesc> h_ops;
     std::vector<host::GenOp> gens;
     // built-in-generator columns (aux.hpp)
@@ -521,15 +522,21 @@ struct p2e_ctx {
     bool fb_run = false;
     // A run is walked by ONE lane, so a launch of r runs has only r * n/64 waves: below this batch size the
     // 1024 SIMDs are better filled by one workgroup row per op (2^10 glv_mul fills: 3.0 ms against 9.5 ms)
-    size_t runs_min_n = 49152;
+    size_t runs_min_n = 14337;              // (= every batch the four-lane plan does not take, see quad_max_n)
+    size_t cp_runs_min_n = 49152;           // the same threshold for the curve programs (curve_api.inc), measured there only at 2^13 / 2^16
     // Below this batch size phases A and B are latency, not throughput: four lanes per signature walk the chains
     // (k_chains_quad) and every inversion batch is cut into 2^binv_split_log2 sub-ranges (k_batch_inv_split)
-    size_t quad_max_n = 24576;
+    // (24 576 until phase B of the lane-per-signature plan went onto two streams below binv_alt_max_n: since then that plan
+    // wins from 2^14 up -- 3.94 against 4.60 ms at 16 384, 4.96 against 6.46 ms at 24 576, 3.81 against 3.62 ms at 12 288)
+    size_t quad_max_n = 14336;
     // Between the two plans (lane per signature, but fewer than one chain wave per SIMD) phase B is the serial resource:
     // its kernels are latency-bound (half a wave per SIMD at 2^15) and queue on one stream from the first piece to the
     // last, with every expansion waiting behind them.  Below this batch size the inversion batches of consecutive pieces
     // alternate between two streams -- and are cut into 2^binv_mid_split_log2 sub-ranges each -- so that they overlap.
     size_t binv_alt_max_n = 49152;
+    // ... and the loop is cut into fewer pieces of longer runs there (5 pieces of 12-iteration runs instead of 8 of 9:
+    // 5.96 against 6.45 ms at 2^15, 7.65 against 7.95 ms at 40 960, 9.15 against 9.53 ms at 48 896)
+    int msm_pieces_mid = 5, run_iters_mid = 12;
     int binv_mid_split_log2 = 1;   // 2^15 per call: 7.03-7.08 ms on one stream, 6.76-6.83 alternating, 6.68-6.72 alternating and split in two
     int binv_split_log2 = 2;
     // small-batch plan: dynamic LDS bytes requested by the expansion kernels (they do not use it): caps how many of
@@ -700,6 +707,15 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     if (const char* env = getenv("P2E_RUNS_MIN_N")) c->runs_min_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_QUAD_MAX_N")) c->quad_max_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_BINV_ALT_MAX_N")) c->binv_alt_max_n = (size_t)strtoull(env, nullptr, 10);
+    if (const char* env = getenv("P2E_CP_RUNS_MIN_N")) c->cp_runs_min_n = (size_t)strtoull(env, nullptr, 10);
+    if (const char* env = getenv("P2E_MSM_PIECES_MID")) {
+        int v = atoi(env);
+        if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->msm_pieces_mid = v;
+    }
+    if (const char* env = getenv("P2E_RUN_ITERS_MID")) {
+        int v = atoi(env);
+        if (v >= 0 && v <= MSM_DIGITS) c->run_iters_mid = v;
+    }
     if (const char* env = getenv("P2E_BINV_MID_SPLIT_LOG2")) {
         int v = atoi(env);
         if (v >= 0 && v <= 3) c->binv_mid_split_log2 = v;
@@ -757,6 +773,9 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         HIP_TRY(hipMemcpy(c->progs[p].d_compact_map, HP.compact_map.data(), sizeof(u32) * HP.compact_map.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc(&c->progs[p].d_wide_before, sizeof(u32) * HP.wide_before.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_wide_before, HP.wide_before.data(), sizeof(u32) * HP.wide_before.size(), hipMemcpyHostToDevice));
+        std::vector<OpDesc> mid = host_ops(p, c->run_iters_mid, c->fb_run);
+        HIP_TRY(hipMalloc(&c->progs[p].d_ops_mid, sizeof(OpDesc) * mid.size()));
+        HIP_TRY(hipMemcpy(c->progs[p].d_ops_mid, mid.data(), sizeof(OpDesc) * mid.size(), hipMemcpyHostToDevice));
         std::vector<OpDesc> plain = host_ops(p, 0);
         HIP_TRY(hipMalloc(&c->progs[p].d_ops_plain, sizeof(OpDesc) * plain.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_ops_plain, plain.data(), sizeof(OpDesc) * plain.size(), hipMemcpyHostToDevice));
@@ -810,6 +829,7 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
         (void)hipFree(p.d_gate_items);
         (void)hipFree(p.d_ops);
         (void)hipFree(p.d_ops_plain);
+        (void)hipFree(p.d_ops_mid);
         (void)hipFree(p.d_aux_items);
         (void)hipFree(p.d_aux_tab);
         (void)hipFree(p.d_compact_map);
@@ -1251,8 +1271,11 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     B.src = (uint16_t*)(base + L.src);
     B.cpts = c->d_cpts;
     B.fbtab = c->d_fbtab;
-    const int run_iters = n >= c->runs_min_n ? c->run_iters : 0;
-    B.ops = run_iters > 0 ? DP.d_ops : DP.d_ops_plain;
+    // three regimes: four lanes per signature (n <= quad_max_n), lane per signature with phase B on two streams and longer
+    // runs in fewer pieces (below binv_alt_max_n), and the large-batch plan
+    const bool mid_plan = n > c->quad_max_n && n < c->binv_alt_max_n;
+    const int run_iters = n >= c->runs_min_n ? (mid_plan ? c->run_iters_mid : c->run_iters) : 0;
+    B.ops = run_iters > 0 ? (mid_plan ? DP.d_ops_mid : DP.d_ops) : DP.d_ops_plain;
     ZERO_COUNTER(c);
     unsigned gx = (unsigned)((n + BS - 1) / BS);
     c->n_expand = 0;
@@ -1312,7 +1335,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     const bool verify = G.num_chains == 3;
     // small batches: four lanes per signature in phase A, split inversion batches in phase B (quad.hpp)
     const bool quad = n <= c->quad_max_n;
-    const int msm_pieces = quad ? c->msm_pieces_small : c->msm_pieces;
+    const int msm_pieces = quad ? c->msm_pieces_small : mid_plan ? c->msm_pieces_mid : c->msm_pieces;
     // with run expansion the fixed-base chain is ONE piece: its windows keep no X, Y / affine form in memory
     // (F_NO_AFFINE), so nothing could resume the chain from scratch in the middle
     const bool fb_run = run_iters > 0 && verify && c->fb_run && G.fb_begin == G.chain_begin[1];
