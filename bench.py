@@ -33,7 +33,8 @@ Extra objects on the line:
                host cores of this box.  kind "port": the Rust reference cannot be built offline.
   cpu_baseline_optimised   the same C code with Montgomery batch inversion across lock-step groups of 256
                signatures (BASELINE.md section 2 variant b): the baseline a careful CPU implementation would set.
-  checked_vs_oracle   signatures of the LAST timed output buffer compared column by column with the C oracle.
+  checked_vs_oracle   signatures of the LAST timed output buffer compared column by column with the C oracle (default:
+               every signature of the batch, after the timed region).
   p256_verify  (N = 1) the widened path on the same line: verify_p256_message_circuit (gadgets/ecdsa.rs:55-78) as a curve
                program, batch 2^16, 115 557 columns per fill: fills/s (median of 5 synchronous calls), whole-fill share of
                the HBM peak, and the expansion kernels' share from the library's HIP-event pairs.  Outside the timed
@@ -177,7 +178,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--allgather-reps", type=int, default=2, help="strong, N>1: timed repetitions of the full-matrix all-gather")
     ap.add_argument("--no-limb-split", action="store_true", help="skip the limb-split roofline leg")
-    ap.add_argument("--check", type=int, default=16, help="signatures of the last output buffer compared with the oracle")
+    ap.add_argument("--check", type=int, default=1 << 16,
+                    help="signatures of the last output buffer compared with the oracle, every column (default: the whole batch)")
     ap.add_argument("--allgather-cols", type=int, default=0,
                     help="N>1 only: after the timed region, all-gather this many columns over RCCL and report GB/s")
     ap.add_argument("--ld-pad", type=int, default=16, help="column stride = batch + this many elements")
@@ -349,11 +351,24 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_c
         last = cols_bufs[(issued[0] - 1) % depth] if issued[0] else cols_bufs[0]
-        sample = np.unique(np.linspace(0, n - 1, min(args.check, n)).astype(np.int64))
-        want, werr, wflags = oracle_c.verify_witness(*[a[sample] for a in sigs])
-        got = last[:, torch.from_numpy(sample).to(dev)].cpu().numpy().view(np.uint64)
-        assert np.array_equal(got, want) and not werr.any() and wflags.all(), "GPU columns differ from the oracle"
-        checked = int(len(sample))
+        cores = usable_cores(oracle_c.max_threads())
+        if args.check >= n:
+            # the whole batch: contiguous chunks through the oracle's lock-step walk (bit-identical to the faithful walk,
+            # tests/test_oracle.py::test_optimised_cpu_variant_is_bit_identical), compared on the GPU
+            checked = 0
+            for a in range(0, n, 4096):
+                b = min(n, a + 4096)
+                want, werr, wflags = oracle_c.verify_witness_lockstep(*[x[a:b] for x in sigs], nthreads=cores)
+                assert not werr.any() and wflags.all()
+                assert torch.equal(last[:, a:b], torch.from_numpy(want.view(np.int64)).to(dev)), \
+                    f"GPU columns differ from the oracle in signatures [{a}, {b})"
+                checked += b - a
+        else:
+            sample = np.unique(np.linspace(0, n - 1, min(args.check, n)).astype(np.int64))
+            want, werr, wflags = oracle_c.verify_witness_lockstep(*[a[sample] for a in sigs], nthreads=cores)
+            got = last[:, torch.from_numpy(sample).to(dev)].cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, want) and not werr.any() and wflags.all(), "GPU columns differ from the oracle"
+            checked = int(len(sample))
 
     limb_split = None
     if rank == 0 and not args.no_limb_split:

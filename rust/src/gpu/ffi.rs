@@ -62,7 +62,6 @@ pub const P2E_WIRE_SRC_UX: u32 = 0x8000_0000;
 pub const P2E_WIRE_SRC_GATE: u32 = 0xC000_0000;
 pub const P2E_COMPACT_WIDE: u32 = 0x8000_0000;
 
-#[link(name = "p2e_hip")]
 /// one built circuit of a curve program (include/p2e.h p2e_curve_program)
 #[repr(C)]
 pub struct P2eCurveProgram {
@@ -74,6 +73,9 @@ pub const P2E_CP_WINDOWED_MUL: i32 = 1;
 pub const P2E_CP_SCALAR_MUL: i32 = 2;
 pub const P2E_CP_VERIFY: i32 = 3;
 
+// tests/test_ffi_surface.py parses this block and include/p2e.h and requires the same symbols, argument counts and
+// integer widths: add a declaration here whenever the header gains one.
+#[link(name = "p2e_hip")]
 extern "C" {
     // ---- context
     pub fn p2e_ctx_create(device: i32, flags: u32, stream: *mut c_void, out: *mut *mut P2eCtx) -> i32;
@@ -81,6 +83,8 @@ extern "C" {
     pub fn p2e_sync(ctx: *mut P2eCtx) -> i32;
     pub fn p2e_last_error() -> *const c_char;
     pub fn p2e_scratch_bytes(program: i32, n: usize) -> usize;
+    // per-phase / per-kernel HIP-event timings of the last fused call on this context (bench.py's roofline figures)
+    pub fn p2e_last_phase_ms(ctx: *mut P2eCtx, out: *mut f32, cap: i32) -> i32;
 
     // ---- the fused schedules: every hot-path run_once of one circuit instance per batch element
     // gadgets/ecdsa.rs:30-53 (gates/mul_nonnative.rs:249-324,513-531; gadgets/nonnative.rs:626-645,696-728,792-810,
@@ -92,6 +96,8 @@ extern "C" {
         err: *mut u8, valid: *mut u8) -> i64;
     pub fn p2e_glv_mul_witness_batch(ctx: *mut P2eCtx, px32: *const u8, py32: *const u8, k32: *const u8, cols: *mut u64,
         n: usize, ld: usize, err: *mut u8, valid: *mut u8) -> i64;
+    pub fn p2e_glv_mul_witness_compact_batch(ctx: *mut P2eCtx, px32: *const u8, py32: *const u8, k32: *const u8,
+        narrow: *mut u32, ld_narrow: usize, wide: *mut u64, ld_wide: usize, n: usize, err: *mut u8, valid: *mut u8) -> i64;
     // the circuit's verdict alone (curve/ecdsa.rs:42-62 verify_message with the circuit's semantics)
     pub fn p2e_ecdsa_verify_batch(ctx: *mut P2eCtx, msg32: *const u8, r32: *const u8, s32: *const u8, pkx32: *const u8,
         pky32: *const u8, n: usize, err: *mut u8, valid: *mut u8) -> i64;
@@ -118,11 +124,15 @@ extern "C" {
     // ---- the targets other generators fill on the same path
     pub fn p2e_aux_witness_batch(ctx: *mut P2eCtx, program: i32, pky32: *const u8, cols: *const u64, ld: usize, aux: *mut u64,
         ld_aux: usize, n: usize, err: *mut u8) -> i64;
+    pub fn p2e_aux_witness_compact_batch(ctx: *mut P2eCtx, program: i32, pky32: *const u8, narrow: *const u32,
+        ld_narrow: usize, aux32: *mut u32, ld_aux: usize, n: usize, err: *mut u8) -> i64;
     pub fn p2e_aux_describe(program: i32, out: *mut P2eAuxDesc, cap: usize) -> i64;
+    pub fn p2e_aux_num_cols(program: i32) -> i64;
     pub fn p2e_ux_witness_batch(ctx: *mut P2eCtx, program: i32, msg32: *const u8, r32: *const u8, s32: *const u8,
         pkx32: *const u8, pky32: *const u8, cols: *const u64, ld: usize, aux: *const u64, ld_aux: usize, ux: *mut c_void,
         ux_u32: i32, ld_ux: usize, n: usize, err: *mut u8) -> i64;
     pub fn p2e_ux_describe(program: i32, out: *mut P2eUxDesc, cap: usize) -> i64;
+    pub fn p2e_ux_num_cols(program: i32) -> i64;
 
     // ---- wire-matrix assembly (rank 3)
     pub fn p2e_wire_map_create(ctx: *mut P2eCtx, program: i32, entries: *const P2eWireMapEntry, count: usize, num_wires: u32,
@@ -133,9 +143,11 @@ extern "C" {
         wire_stride: usize, n: usize) -> i64;
     pub fn p2e_gate_internal_batch(ctx: *mut P2eCtx, program: i32, aux: *const u64, ld_aux: usize, gate: *mut u64,
         ld_gate: usize, n: usize) -> i64;
+    pub fn p2e_gate_internal_num_cols(program: i32) -> i64;
 
     // ---- column maps (host only)
     pub fn p2e_schedule_describe(program: i32, out: *mut P2eGenDesc, cap: usize) -> i64;
+    pub fn p2e_schedule_num_cols(program: i32) -> i64;
     pub fn p2e_schedule_wiring(program: i32, out: *mut P2eGenWiring, cap: usize) -> i64;
     pub fn p2e_wiring_const(id: u32, out32: *mut u8) -> i32;
     pub fn p2e_compact_layout(program: i32, col_map: *mut u32, cap: usize, num_narrow: *mut u32, num_wide: *mut u32) -> i64;
@@ -145,6 +157,14 @@ extern "C" {
         row_ld: usize) -> i64;
     pub fn p2e_columns_compact(ctx: *mut P2eCtx, program: i32, cols: *const u64, ld: usize, n: usize, narrow: *mut u32,
         ld_narrow: usize, wide: *mut u64, ld_wide: usize, err: *mut u8) -> i64;
+    pub fn p2e_compact_to_rows(ctx: *mut P2eCtx, program: i32, narrow: *const u32, ld_narrow: usize, wide: *const u64,
+        ld_wide: usize, n: usize, rows_narrow: *mut u32, row_ld_narrow: usize, rows_wide: *mut u64, row_ld_wide: usize) -> i64;
+
+    // ---- synthetic inputs (host only): valid signatures per curve/ecdsa.rs:25-40
+    pub fn p2e_synth_signatures(seed: u64, first: usize, n: usize, msg32: *mut u8, r32: *mut u8, s32: *mut u8, pkx32: *mut u8,
+        pky32: *mut u8) -> i32;
+    pub fn p2e_synth_signatures_curve(curve: i32, seed: u64, first: usize, n: usize, msg32: *mut u8, r32: *mut u8, s32: *mut u8,
+        pkx32: *mut u8, pky32: *mut u8) -> i32;
 
     // ---- curve programs (rank 4): curve_scalar_mul_windowed / curve_scalar_mul on either curve, verify_p256_message_circuit
     pub fn p2e_curve_program_create(ctx: *mut P2eCtx, kind: i32, curve: i32, blind_x32: *const u8, blind_y32: *const u8,
