@@ -208,6 +208,44 @@ def glv_mul_witness_aux(px, py, k, nthreads=0):
     return cols, aux, err, flags
 
 
+CP_WINDOWED_MUL, CP_SCALAR_MUL, CP_VERIFY = 1, 2, 3
+
+
+def curve_program_num_cols(kind, curve):
+    """(num_cols, num_aux) of a curve program, by a dry walk (p2e_oracle.h p2e_oracle_curve_program_num_cols)."""
+    f = lib().p2e_oracle_curve_program_num_cols
+    f.restype = C.c_long
+    na = C.c_long()
+    nc = f(C.c_int(kind), C.c_int(curve), C.byref(na))
+    assert nc > 0
+    return int(nc), int(na.value)
+
+
+def curve_program(kind, curve, blind, args, nthreads=0, lockstep=0, want_aux=True):
+    """The crate's other scalar multiplications (p2e_oracle.h p2e_oracle_curve_program).  blind: (x, y) python ints or
+    two 32-byte arrays; args: (px, py, k) for kinds 1, 2 or (msg, r, s, pkx, pky) for kind 3, each (n, 32) uint8.
+    Returns (cols, aux, err, flags)."""
+    bx, by = [np.frombuffer(int(v).to_bytes(32, "little"), dtype=np.uint8).copy() if isinstance(v, int) else
+              np.ascontiguousarray(v, dtype=np.uint8) for v in blind]
+    if len(args) == 3:
+        px, py, k = [np.ascontiguousarray(a, dtype=np.uint8) for a in args]
+        msg = r = s = k
+    else:
+        msg, r, s, px, py = [np.ascontiguousarray(a, dtype=np.uint8) for a in args]
+    n = px.shape[0]
+    nc, na = curve_program_num_cols(kind, curve)
+    cols = _cols(nc, n)
+    aux = _cols(na, n) if want_aux else None
+    err, flags = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    f = lib().p2e_oracle_curve_program
+    f.restype = C.c_long
+    rc = f(C.c_int(kind), C.c_int(curve), _p(bx), _p(by), _p(msg), _p(r), _p(s), _p(px), _p(py), _p(cols), C.c_size_t(n),
+           C.c_size_t(n), _p(aux) if want_aux else None, C.c_size_t(n), _p(err), _p(flags), C.c_int(nthreads), C.c_int(lockstep))
+    if rc < 0:
+        raise RuntimeError(f"p2e_oracle_curve_program: {rc}")
+    return cols, aux, err, flags
+
+
 def rando():
     x = np.zeros(32, dtype=np.uint8)
     y = np.zeros(32, dtype=np.uint8)

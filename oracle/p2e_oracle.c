@@ -143,7 +143,30 @@ static const uint8_t HASH0_LE[32] = {0x01, 0x1b, 0x4d, 0x03, 0xdd, 0x8c, 0x01, 0
                                      0xcf, 0x9c, 0x4c, 0x81, 0x7e, 0x4b, 0x16, 0x7f, 0x1d, 0x1b, 0x83,
                                      0xe5, 0xc6, 0xf0, 0xf1, 0x0d, 0x89, 0xba, 0x1e, 0x7b, 0xce};
 
-static const w32 *modulus_of(int field) { return field == P2E_O_FIELD_SCALAR ? MOD_N : MOD_P; }
+/* NIST P-256: field/p256_base.rs:14-17, field/p256_scalar.rs:5-9, curve/p256.rs:15-57 */
+static const w32 MOD_P256[8] = {0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0x00000000,
+                                0x00000000, 0x00000000, 0x00000001, 0xFFFFFFFF};
+static const w32 MOD_N256[8] = {0xFC632551, 0xF3B9CAC2, 0xA7179E84, 0xBCE6FAAD,
+                                0xFFFFFFFF, 0xFFFFFFFF, 0x00000000, 0xFFFFFFFF};
+static const w32 P256_A[8] = {W64(0xFFFFFFFFFFFFFFFCull), W64(0x00000000FFFFFFFFull), W64(0x0000000000000000ull),
+                              W64(0xFFFFFFFF00000001ull)};
+static const w32 P256_B[8] = {W64(0x3BCE3C3E27D2604Bull), W64(0x651D06B0CC53B0F6ull), W64(0xB3EBBD55769886BCull),
+                              W64(0x5AC635D8AA3A93E7ull)};
+static const w32 P256_GX[8] = {W64(0xF4A13945D898C296ull), W64(0x77037D812DEB33A0ull), W64(0xF8BCE6E563A440F2ull),
+                               W64(0x6B17D1F2E12C4247ull)};
+static const w32 P256_GY[8] = {W64(0xCBB6406837BF51F5ull), W64(0x2BCE33576B315ECEull), W64(0x8EE7EB4A7C0F9E16ull),
+                               W64(0x4FE342E2FE1A7F9Bull)};
+static const w32 SECP_A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static const w32 SECP_B[8] = {7, 0, 0, 0, 0, 0, 0, 0};
+
+static const w32 *modulus_of(int field) {
+    switch (field) {
+    case P2E_O_FIELD_SCALAR: return MOD_N;
+    case P2E_O_FIELD_P256_BASE: return MOD_P256;
+    case P2E_O_FIELD_P256_SCALAR: return MOD_N256;
+    default: return MOD_P;
+    }
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* prime-field ops the way the reference does them: BigUint mul + mod_floor, Fermat inverse     */
@@ -466,106 +489,146 @@ static void gen_glv(const u64 *k_limbs, int nl, u64 *k1l, u64 *k2l, u64 *k1_neg,
 typedef struct {
     w32 x[8], y[8];
 } apt;
-static void ec_double(apt *r, const apt *p) {
+#define FB_WINDOWS 66
+/* one curve of the crate (curve/curve_types.rs:15-42): moduli, a, b, G, and the constants its gadgets derive */
+typedef struct curve_t {
+    int fbase, fscalar;     /* P2E_O_FIELD_* of C::BaseField / C::ScalarField */
+    const w32 *p, *n, *a, *b;
+    apt g;
+    u64 A_L[NL], B_L[NL];   /* constant_nonnative(C::A / C::B): limbs; the COUNT (convert_base, quirk Q5) is a_nl / b_nl */
+    int a_nl, b_nl;
+    apt rando, neg_rando;                   /* KeccakHash::<32>(0) * G, gadgets/curve_fixed_base.rs:34-38 */
+    u64 RANDO_L[2][NL], NEG_RANDO_L[2][NL];
+    u64 FB_TABLE[FB_WINDOWS][16][2][NL];    /* [window][digit][x|y][limb]; slot 0 := slot 1 */
+    apt start25, start25_264;               /* KeccakHash::<25>(0) * G and 2^264 times it, gadgets/curve_windowed_mul.rs:140-153 */
+} curve_t;
+static curve_t SECP, P256C;
+
+static void ecc_double(const curve_t *c, apt *r, const apt *p) {
     w32 l[8], t[8], u[8], x3[8];
-    fe_mulmod(t, p->x, p->x, MOD_P);
-    fe_addmod(u, t, t, MOD_P);
-    fe_addmod(t, u, t, MOD_P); /* 3x^2 */
-    fe_addmod(u, p->y, p->y, MOD_P);
-    fe_invmod(u, u, MOD_P);
-    fe_mulmod(l, t, u, MOD_P);
-    fe_mulmod(x3, l, l, MOD_P);
-    fe_submod(x3, x3, p->x, MOD_P);
-    fe_submod(x3, x3, p->x, MOD_P);
-    fe_submod(t, p->x, x3, MOD_P);
-    fe_mulmod(t, l, t, MOD_P);
-    fe_submod(r->y, t, p->y, MOD_P);
+    fe_mulmod(t, p->x, p->x, c->p);
+    fe_addmod(u, t, t, c->p);
+    fe_addmod(t, u, t, c->p); /* 3x^2 */
+    fe_addmod(t, t, c->a, c->p);
+    fe_addmod(u, p->y, p->y, c->p);
+    fe_invmod(u, u, c->p);
+    fe_mulmod(l, t, u, c->p);
+    fe_mulmod(x3, l, l, c->p);
+    fe_submod(x3, x3, p->x, c->p);
+    fe_submod(x3, x3, p->x, c->p);
+    fe_submod(t, p->x, x3, c->p);
+    fe_mulmod(t, l, t, c->p);
+    fe_submod(r->y, t, p->y, c->p);
     memcpy(r->x, x3, 32);
 }
-static void ec_add(apt *r, const apt *p, const apt *q) {
+static void ecc_add(const curve_t *c, apt *r, const apt *p, const apt *q) {
     w32 l[8], t[8], u[8], x3[8];
-    fe_submod(t, q->y, p->y, MOD_P);
-    fe_submod(u, q->x, p->x, MOD_P);
-    fe_invmod(u, u, MOD_P);
-    fe_mulmod(l, t, u, MOD_P);
-    fe_mulmod(x3, l, l, MOD_P);
-    fe_submod(x3, x3, p->x, MOD_P);
-    fe_submod(x3, x3, q->x, MOD_P);
-    fe_submod(t, p->x, x3, MOD_P);
-    fe_mulmod(t, l, t, MOD_P);
-    fe_submod(r->y, t, p->y, MOD_P);
+    fe_submod(t, q->y, p->y, c->p);
+    fe_submod(u, q->x, p->x, c->p);
+    fe_invmod(u, u, c->p);
+    fe_mulmod(l, t, u, c->p);
+    fe_mulmod(x3, l, l, c->p);
+    fe_submod(x3, x3, p->x, c->p);
+    fe_submod(x3, x3, q->x, c->p);
+    fe_submod(t, p->x, x3, c->p);
+    fe_mulmod(t, l, t, c->p);
+    fe_submod(r->y, t, p->y, c->p);
     memcpy(r->x, x3, 32);
 }
-static void ec_neg(apt *r, const apt *p) {
+static void ecc_neg(const curve_t *c, apt *r, const apt *p) {
     w32 z[8] = {0};
     memcpy(r->x, p->x, 32);
-    fe_submod(r->y, z, p->y, MOD_P);
+    fe_submod(r->y, z, p->y, c->p);
 }
-static void ec_mul(apt *r, const w32 *k, const apt *p) {
+/* k * p for an integer k < 2^256 (NOT reduced: from_noncanonical_biguint keeps the hash as it is); k != 0 */
+static void ecc_mul(const curve_t *c, apt *r, const w32 *k, const apt *p) {
     apt acc, base = *p;
     int have = 0;
     for (int i = 0; i < 256; i++) {
         if ((k[i >> 5] >> (i & 31)) & 1) {
             if (have)
-                ec_add(&acc, &acc, &base);
+                ecc_add(c, &acc, &acc, &base);
             else {
                 acc = base;
                 have = 1;
             }
         }
-        ec_double(&base, &base);
+        ecc_double(c, &base, &base);
     }
     *r = acc;
 }
 
-#define FB_WINDOWS 66
 static apt RANDO, NEG_RANDO, NEG_RANDO_146;
-static u64 FB_TABLE[FB_WINDOWS][16][2][NL]; /* [window][digit][x|y][limb]; slot 0 := slot 1 */
-static u64 RANDO_L[2][NL], NEG_RANDO_L[2][NL], NEG_RANDO_146_L[2][NL], BETA_L[NL], GLV_S_L[NL], B7_L[NL];
+static u64 RANDO_L[2][NL], NEG_RANDO_L[2][NL], NEG_RANDO_146_L[2][NL], BETA_L[NL], GLV_S_L[NL];
 static int INIT_DONE = 0;
 
 static void point_limbs(const apt *p, u64 out[2][NL]) {
     words_to_limbs(p->x, 8, out[0], NL);
     words_to_limbs(p->y, 8, out[1], NL);
 }
+/* limbs constant_biguint gives a constant (convert_base gadgets/biguint.rs:27-51: no zero limbs on top) */
+static int const_nlimbs(const u64 *l) {
+    int n = NL;
+    while (n > 0 && l[n - 1] == 0) n--;
+    return n;
+}
+static void curve_init(curve_t *c, int fbase, int fscalar, const w32 *a, const w32 *b, const w32 *gx, const w32 *gy) {
+    c->fbase = fbase, c->fscalar = fscalar;
+    c->p = modulus_of(fbase), c->n = modulus_of(fscalar), c->a = a, c->b = b;
+    memcpy(c->g.x, gx, 32);
+    memcpy(c->g.y, gy, 32);
+    words_to_limbs(a, 8, c->A_L, NL);
+    words_to_limbs(b, 8, c->B_L, NL);
+    c->a_nl = const_nlimbs(c->A_L), c->b_nl = const_nlimbs(c->B_L);
+    w32 h[8];
+    bytes_to_words(HASH0_LE, h);
+    ecc_mul(c, &c->rando, h, &c->g);
+    ecc_neg(c, &c->neg_rando, &c->rando);
+    point_limbs(&c->rando, c->RANDO_L);
+    point_limbs(&c->neg_rando, c->NEG_RANDO_L);
+    /* KeccakHash::<25>: the first 25 bytes of the same digest (gadgets/curve_windowed_mul.rs:140-144) */
+    uint8_t h25[32];
+    memset(h25, 0, sizeof h25);
+    memcpy(h25, HASH0_LE, 25);
+    bytes_to_words(h25, h);
+    ecc_mul(c, &c->start25, h, &c->g);
+    apt d = c->start25;
+    for (int i = 0; i < 4 * FB_WINDOWS; i++) ecc_double(c, &d, &d); /* windows.len() * 4 doublings, :146-152 */
+    c->start25_264 = d; /* the gadget negates it itself (curve_neg of the constant, :168-169) */
+    /* gadgets/curve_fixed_base.rs:24-30,45-56 */
+    apt base = c->g;
+    for (int w = 0; w < FB_WINDOWS; w++) {
+        apt acc = base;
+        for (int t = 1; t < 16; t++) {
+            point_limbs(&acc, c->FB_TABLE[w][t]);
+            if (t == 1) point_limbs(&acc, c->FB_TABLE[w][0]);
+            if (t < 15) {
+                if (t == 1)
+                    ecc_double(c, &acc, &acc);
+                else
+                    ecc_add(c, &acc, &acc, &base);
+            }
+        }
+        for (int i = 0; i < 4; i++) ecc_double(c, &base, &base);
+    }
+}
 static void oracle_init(void) {
 #pragma omp critical(p2e_oracle_init)
     {
         if (!INIT_DONE) {
             INV_2_29 = gl_pow(1ull << BITS, P_GL - 2);
-            apt g;
-            memcpy(g.x, GEN_X, 32);
-            memcpy(g.y, GEN_Y, 32);
-            w32 h[8];
-            bytes_to_words(HASH0_LE, h);
-            ec_mul(&RANDO, h, &g);
-            ec_neg(&NEG_RANDO, &RANDO);
+            curve_init(&SECP, P2E_O_FIELD_BASE, P2E_O_FIELD_SCALAR, SECP_A, SECP_B, GEN_X, GEN_Y);
+            curve_init(&P256C, P2E_O_FIELD_P256_BASE, P2E_O_FIELD_P256_SCALAR, P256_A, P256_B, P256_GX, P256_GY);
+            RANDO = SECP.rando;
+            NEG_RANDO = SECP.neg_rando;
             apt d = RANDO;
-            for (int i = 0; i < 146; i++) ec_double(&d, &d); /* gadgets/curve_msm.rs:74 (2*73 doublings) */
-            ec_neg(&NEG_RANDO_146, &d);
+            for (int i = 0; i < 146; i++) ecc_double(&SECP, &d, &d); /* gadgets/curve_msm.rs:74 (2*73 doublings) */
+            ecc_neg(&SECP, &NEG_RANDO_146, &d);
             point_limbs(&RANDO, RANDO_L);
             point_limbs(&NEG_RANDO, NEG_RANDO_L);
             point_limbs(&NEG_RANDO_146, NEG_RANDO_146_L);
             words_to_limbs(GLV_BETA, 8, BETA_L, NL);
             words_to_limbs(GLV_S, 8, GLV_S_L, NL);
-            memset(B7_L, 0, sizeof B7_L);
-            B7_L[0] = 7;
-            /* gadgets/curve_fixed_base.rs:24-30,45-56 */
-            apt base = g;
-            for (int w = 0; w < FB_WINDOWS; w++) {
-                apt acc = base;
-                for (int t = 1; t < 16; t++) {
-                    point_limbs(&acc, FB_TABLE[w][t]);
-                    if (t == 1) point_limbs(&acc, FB_TABLE[w][0]);
-                    if (t < 15) {
-                        if (t == 1)
-                            ec_double(&acc, &acc);
-                        else
-                            ec_add(&acc, &acc, &base);
-                    }
-                }
-                for (int i = 0; i < 4; i++) ec_double(&base, &base);
-            }
             INIT_DONE = 1;
         }
     }
@@ -589,11 +652,13 @@ typedef struct {
      * a separate column matrix, NULL = not wanted */
     u64 *aux;
     size_t ald, acol;
+    const struct curve_t *cv; /* NULL = secp256k1 */
 } walker;
+static const curve_t *cv_of(const walker *w) { return w->cv ? w->cv : &SECP; }
 
 static void aux_emit(walker *w, const u64 *v, int n) {
-    if (!w->aux) return;
-    for (int i = 0; i < n; i++) w->aux[(w->acol + (size_t)i) * w->ald + w->idx] = v[i];
+    if (w->aux)
+        for (int i = 0; i < n; i++) w->aux[(w->acol + (size_t)i) * w->ald + w->idx] = v[i];
     w->acol += (size_t)n;
 }
 static u64 w_not(walker *w, u64 b) { /* builder.not(b) = 1 - b */
@@ -608,7 +673,8 @@ static u64 w_is_zero(walker *w, u64 x) { /* builder.is_equal(x, zero) */
 }
 
 static void emit(walker *w, const u64 *v, int n) {
-    for (int i = 0; i < n; i++) w->out[(w->col + (size_t)i) * w->ld + w->idx] = v[i];
+    if (w->out)
+        for (int i = 0; i < n; i++) w->out[(w->col + (size_t)i) * w->ld + w->idx] = v[i];
     w->col += (size_t)n;
 }
 static nn w_add(walker *w, const nn *a, const nn *b, int field) {
@@ -671,7 +737,7 @@ static nn w_cond_neg(walker *w, const nn *x, int nl, u64 b, int field) { /* gadg
     return w_add(w, &t, &f, field);
 }
 static pt w_curve_add(walker *w, const pt *p1, const pt *p2) { /* gadgets/curve.rs:202-223 */
-    const int F = P2E_O_FIELD_BASE;
+    const int F = cv_of(w)->fbase;
     nn u = w_sub(w, &p2->y, &p1->y, F);
     nn v = w_sub(w, &p2->x, &p1->x, F);
     nn vi = w_inv(w, &v, F);
@@ -686,19 +752,20 @@ static pt w_curve_add(walker *w, const pt *p1, const pt *p2) { /* gadgets/curve.
     return r;
 }
 static pt w_curve_double(walker *w, const pt *p) { /* gadgets/curve.rs:160-185 */
-    const int F = P2E_O_FIELD_BASE;
+    const curve_t *cv = cv_of(w);
+    const int F = cv->fbase;
     nn dy = w_add(w, &p->y, &p->y, F);
     nn idy = w_inv(w, &dy, F);
     nn xx = w_mul(w, &p->x, &p->x, F);
     u64 summ[4][NL];
-    int nls[4] = {NL, NL, NL, 0};
+    int nls[4] = {NL, NL, NL, cv->a_nl};
     memcpy(summ[0], xx.l, sizeof xx.l);
     memcpy(summ[1], xx.l, sizeof xx.l);
     memcpy(summ[2], xx.l, sizeof xx.l);
-    memset(summ[3], 0, sizeof summ[3]); /* A = 0 */
+    memcpy(summ[3], cv->A_L, sizeof summ[3]); /* constant_nonnative(C::A): 0 limbs on secp256k1 */
     nn t;
     u64 ov;
-    gen_add_many((const u64(*)[NL])summ, nls, 4, MOD_P, t.l, &ov, &w->err);
+    gen_add_many((const u64(*)[NL])summ, nls, 4, cv->p, t.l, &ov, &w->err);
     emit(w, t.l, NL);
     emit(w, &ov, 1);
     nn l = w_mul(w, &t, &idy, F);
@@ -720,8 +787,8 @@ static pt w_curve_cond_add(walker *w, const pt *p1, int nlx, int nly, const pt *
     nn xf = w_mul_bool(w, &p1->x, nlx, not_b);
     nn yf = w_mul_bool(w, &p1->y, nly, not_b);
     pt r;
-    r.x = w_add(w, &xt, &xf, P2E_O_FIELD_BASE);
-    r.y = w_add(w, &yt, &yf, P2E_O_FIELD_BASE);
+    r.x = w_add(w, &xt, &xf, cv_of(w)->fbase);
+    r.y = w_add(w, &yt, &yf, cv_of(w)->fbase);
     return r;
 }
 static pt pt_from(u64 l[2][NL]) {
@@ -754,13 +821,9 @@ static void aux_point(walker *w, const pt *p) {
     aux_emit(w, p->x.l, NL);
     aux_emit(w, p->y.l, NL);
 }
-/* limbs constant_biguint gives a constant (convert_base gadgets/biguint.rs:27-51: no zero limbs on top) */
-static int const_nlimbs(const u64 *l) {
-    int n = NL;
-    while (n > 0 && l[n - 1] == 0) n--;
-    return n;
-}
-static pt w_fixed_base(walker *w, const nn *scalar) { /* gadgets/curve_fixed_base.rs:18-66 */
+static pt w_fixed_base(walker *w, const nn *scalar) { /* gadgets/curve_fixed_base.rs:18-66; base = the curve's generator */
+    const curve_t *cv = cv_of(w);
+    u64(*RANDO_L)[NL] = (u64(*)[NL])cv->RANDO_L, (*NEG_RANDO_L)[NL] = (u64(*)[NL])cv->NEG_RANDO_L;
     pt result = pt_from(RANDO_L);
     int nlx = const_nlimbs(RANDO_L[0]), nly = const_nlimbs(RANDO_L[1]);
     /* split_nonnative_to_4_bit_limbs gadgets/split_nonnative.rs:25-50 */
@@ -773,7 +836,7 @@ static pt w_fixed_base(walker *w, const nn *scalar) { /* gadgets/curve_fixed_bas
     for (int i = 0; i < FB_WINDOWS; i++) {
         unsigned d = digit_of(scalar->l, NL, 4, i);
         u64 should_add = w_not(w, w_is_zero(w, d));
-        pt r = pt_from(FB_TABLE[i][d]);
+        pt r = pt_from((u64(*)[NL])cv->FB_TABLE[i][d]);
         aux_point(w, &r);
         result = w_curve_cond_add(w, &result, nlx, nly, &r, should_add);
         nlx = nly = NL;
@@ -863,7 +926,7 @@ static void walk_verify(walker *w, const uint8_t *msg32, const uint8_t *r32, con
     pk.y = nn_from_bytes(pky32);
     int ok = 1;
     /* curve_assert_valid gadgets/curve.rs:123-135 */
-    nn a0 = nn_zero(), b7 = nn_from(B7_L);
+    nn a0 = nn_zero(), b7 = nn_from(SECP.B_L);
     nn y2 = w_mul(w, &pk.y, &pk.y, F);
     nn x2 = w_mul(w, &pk.x, &pk.x, F);
     nn x3 = w_mul(w, &x2, &pk.x, F);
@@ -882,6 +945,126 @@ static void walk_verify(walker *w, const uint8_t *msg32, const uint8_t *r32, con
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* curve programs: curve_scalar_mul_windowed, curve_scalar_mul, verify_p256_message_circuit    */
+/* ------------------------------------------------------------------------------------------ */
+static pt pt_from_apt(const apt *a) {
+    u64 l[2][NL];
+    point_limbs(a, l);
+    return pt_from(l);
+}
+/* gadgets/curve.rs:137-147: neg_nonnative(y) = sub(zero, y), the zero constant has 0 limbs (nonnative.rs:496-499) */
+static pt w_curve_neg(walker *w, const pt *p) {
+    nn z = nn_zero();
+    pt r;
+    r.x = p->x;
+    r.y = w_sub(w, &z, &p->y, cv_of(w)->fbase);
+    return r;
+}
+/* split_nonnative_to_4_bit_limbs gadgets/split_nonnative.rs:25-50: the bits, then (lower, upper, limb) per nibble */
+static void aux_split4(walker *w, const nn *scalar) {
+    aux_bits(w, scalar->l, NL);
+    for (int i = 0; i < FB_WINDOWS; i++) {
+        u64 d = digit_of(scalar->l, NL, 4, i);
+        u64 c[3] = {d & 3, d >> 2, d};
+        aux_emit(w, c, 3);
+    }
+}
+/* gadgets/curve_windowed_mul.rs:131-173; g = the rand() point of precompute_window (:57) */
+static pt w_windowed_mul(walker *w, const pt *p, const nn *n, const apt *g) {
+    const curve_t *cv = cv_of(w);
+    aux_split4(w, n);
+    /* precompute_window :52-72 */
+    apt neg_g;
+    ecc_neg(cv, &neg_g, g);
+    pt pre[16], neg = pt_from_apt(&neg_g);
+    pre[0] = pt_from_apt(g);
+    for (int i = 1; i < 16; i++) pre[i] = w_curve_add(w, p, &pre[i - 1]);
+    for (int i = 1; i < 16; i++) pre[i] = w_curve_add(w, &neg, &pre[i]);
+    pt result = pt_from_apt(&cv->start25);
+    for (int i = FB_WINDOWS - 1; i >= 0; i--) { /* :157-166, most significant window first */
+        for (int k = 0; k < 4; k++) result = w_curve_double(w, &result);
+        unsigned d = digit_of(n->l, NL, 4, i);
+        aux_point(w, &pre[d]); /* random_access_curve_points, then is_equal, then not */
+        u64 should_add = w_not(w, w_is_zero(w, d));
+        result = w_curve_cond_add(w, &result, NL, NL, &pre[d], should_add);
+    }
+    pt to_subtract = pt_from_apt(&cv->start25_264);
+    pt to_add = w_curve_neg(w, &to_subtract);
+    return w_curve_add(w, &result, &to_add);
+}
+/* gadgets/curve.rs:245-285; rando = the rand() blinding point of :253 */
+static pt w_scalar_mul(walker *w, const pt *p, const nn *n, const apt *rando) {
+    const int F = cv_of(w)->fbase;
+    aux_bits(w, n->l, NL); /* split_nonnative_to_bits gadgets/nonnative.rs:566-582 */
+    pt randot = pt_from_apt(rando);
+    pt result = randot; /* add_virtual_affine_point_target + connect: 9 limbs */
+    pt two_i_times_p = *p;
+    for (int i = 0; i < NL * BITS; i++) {
+        u64 bit = (n->l[i / BITS] >> (i % BITS)) & 1;
+        u64 not_bit = w_not(w, bit);
+        pt rp = w_curve_add(w, &result, &two_i_times_p);
+        nn xt = w_mul_bool(w, &rp.x, NL, bit);
+        nn xf = w_mul_bool(w, &result.x, NL, not_bit);
+        nn yt = w_mul_bool(w, &rp.y, NL, bit);
+        nn yf = w_mul_bool(w, &result.y, NL, not_bit);
+        result.x = w_add(w, &xt, &xf, F);
+        result.y = w_add(w, &yt, &yf, F);
+        two_i_times_p = w_curve_double(w, &two_i_times_p);
+    }
+    pt neg_r = w_curve_neg(w, &randot);
+    return w_curve_add(w, &result, &neg_r);
+}
+/* gadgets/ecdsa.rs:55-78 */
+static void walk_verify_p256(walker *w, const uint8_t *msg32, const uint8_t *r32, const uint8_t *s32,
+                             const uint8_t *pkx32, const uint8_t *pky32, const apt *g, uint8_t *flag) {
+    const curve_t *cv = cv_of(w);
+    const int F = cv->fbase, S = cv->fscalar;
+    nn msg = nn_from_bytes(msg32), r = nn_from_bytes(r32), s = nn_from_bytes(s32);
+    pt pk;
+    pk.x = nn_from_bytes(pkx32);
+    pk.y = nn_from_bytes(pky32);
+    int ok = 1;
+    nn a = nn_from(cv->A_L), b = nn_from(cv->B_L); /* curve_assert_valid gadgets/curve.rs:123-135 */
+    nn y2 = w_mul(w, &pk.y, &pk.y, F);
+    nn x2 = w_mul(w, &pk.x, &pk.x, F);
+    nn x3 = w_mul(w, &x2, &pk.x, F);
+    nn ax = w_mul(w, &a, &pk.x, F);
+    nn axb = w_add(w, &ax, &b, F);
+    nn rhs = w_add(w, &x3, &axb, F);
+    ok &= nn_eq(&y2, &rhs);
+    nn c = w_inv(w, &s, S);
+    nn u1 = w_mul(w, &msg, &c, S);
+    nn u2 = w_mul(w, &r, &c, S);
+    pt p1 = w_fixed_base(w, &u1);
+    pt p2 = w_windowed_mul(w, &pk, &u2, g);
+    pt sum = w_curve_add(w, &p1, &p2);
+    ok &= nn_eq(&sum.x, &r);
+    *flag = (uint8_t)ok;
+}
+typedef struct {
+    int kind;
+    const curve_t *cv;
+    apt blind;
+    const uint8_t *msg, *r, *s, *px, *py;
+} cp_job;
+static void walk_curve_program(walker *w, const cp_job *J, size_t i, uint8_t *flag) {
+    w->cv = J->cv;
+    if (J->kind == P2E_O_CP_VERIFY) {
+        walk_verify_p256(w, J->msg + 32 * i, J->r + 32 * i, J->s + 32 * i, J->px + 32 * i, J->py + 32 * i, &J->blind, flag);
+        return;
+    }
+    pt p;
+    p.x = nn_from_bytes(J->px + 32 * i);
+    p.y = nn_from_bytes(J->py + 32 * i);
+    nn k = nn_from_bytes(J->msg + 32 * i);
+    if (J->kind == P2E_O_CP_WINDOWED_MUL)
+        (void)w_windowed_mul(w, &p, &k, &J->blind);
+    else
+        (void)w_scalar_mul(w, &p, &k, &J->blind);
+    *flag = 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* lock-step groups: batch inversion across signatures (optimised-CPU baseline only)            */
 /* ------------------------------------------------------------------------------------------ */
 #define LS_MAX 256
@@ -894,8 +1077,9 @@ typedef struct lockstep {
     int pending[LS_MAX], finished[LS_MAX];
     int cur, count;
     const uint8_t *msg, *r, *s, *pkx, *pky;
-    uint64_t *cols;
-    size_t ld, first;
+    const cp_job *job; /* non-NULL: a curve program instead of verify_secp256k1_message_circuit */
+    uint64_t *cols, *aux;
+    size_t ld, ald, first;
     uint8_t *err, *flags;
 } lockstep;
 
@@ -912,9 +1096,12 @@ static void ls_entry(void) {
     lockstep *L = LS;
     const int k = L->cur;
     const size_t i = L->first + (size_t)k;
-    walker w = {L->cols, L->ld, i, 0, 0, NULL, 0, 0};
+    walker w = {L->cols, L->ld, i, 0, 0, L->aux, L->ald, 0, NULL};
     uint8_t f = 0;
-    walk_verify(&w, L->msg + 32 * i, L->r + 32 * i, L->s + 32 * i, L->pkx + 32 * i, L->pky + 32 * i, &f);
+    if (L->job)
+        walk_curve_program(&w, L->job, i, &f);
+    else
+        walk_verify(&w, L->msg + 32 * i, L->r + 32 * i, L->s + 32 * i, L->pkx + 32 * i, L->pky + 32 * i, &f);
     L->err[i] = w.err;
     if (L->flags) L->flags[i] = f;
     L->finished[k] = 1; /* returning switches to uc_link = main */
@@ -959,6 +1146,8 @@ static void ls_run_group(lockstep *L) {
         if (!live) break;
         ls_batch_invert(L, MOD_P);
         ls_batch_invert(L, MOD_N);
+        ls_batch_invert(L, MOD_P256);
+        ls_batch_invert(L, MOD_N256);
     }
 }
 
@@ -1214,7 +1403,7 @@ long p2e_oracle_verify_witness_aux(const uint8_t *msg, const uint8_t *r, const u
 #endif
 #pragma omp parallel for schedule(dynamic, 1)
     for (size_t i = 0; i < n; i++) {
-        walker w = {cols, ld, i, 0, 0, aux, ald, 0};
+        walker w = {cols, ld, i, 0, 0, aux, ald, 0, NULL};
         uint8_t f = 0;
         walk_verify(&w, msg + 32 * i, r + 32 * i, s + 32 * i, pkx + 32 * i, pky + 32 * i, &f);
         err[i] = w.err;
@@ -1222,10 +1411,9 @@ long p2e_oracle_verify_witness_aux(const uint8_t *msg, const uint8_t *r, const u
     }
     return count_err(err, n);
 }
-long p2e_oracle_verify_witness_lockstep(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
-                                        const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint8_t *err,
-                                        uint8_t *flags, int nthreads, int group) {
-    oracle_init();
+static long run_lockstep(const cp_job *job, const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
+                         const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint64_t *aux, size_t ald, uint8_t *err,
+                         uint8_t *flags, int nthreads, int group) {
     if (group < 1) group = 64;
     if (group > LS_MAX) group = LS_MAX;
 #ifdef _OPENMP
@@ -1245,7 +1433,8 @@ long p2e_oracle_verify_witness_lockstep(const uint8_t *msg, const uint8_t *r, co
         } else {
             L->stack = stack;
             L->msg = msg, L->r = r, L->s = s, L->pkx = pkx, L->pky = pky;
-            L->cols = cols, L->ld = ld, L->err = err, L->flags = flags;
+            L->job = job;
+            L->cols = cols, L->ld = ld, L->aux = aux, L->ald = ald, L->err = err, L->flags = flags;
 #pragma omp for schedule(dynamic, 1)
             for (size_t g = 0; g < ngroups; g++) {
                 L->first = g * (size_t)group;
@@ -1260,6 +1449,67 @@ long p2e_oracle_verify_witness_lockstep(const uint8_t *msg, const uint8_t *r, co
     }
     if (failed) return -1;
     return count_err(err, n);
+}
+long p2e_oracle_verify_witness_lockstep(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
+                                        const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint8_t *err,
+                                        uint8_t *flags, int nthreads, int group) {
+    oracle_init();
+    return run_lockstep(NULL, msg, r, s, pkx, pky, cols, n, ld, NULL, 0, err, flags, nthreads, group);
+}
+static int cp_job_init(cp_job *J, int kind, int curve, const uint8_t *bx, const uint8_t *by) {
+    if (kind < 1 || kind > 3 || curve < 0 || curve > 1 || (kind == P2E_O_CP_VERIFY && curve != 1) || !bx || !by) return -1;
+    oracle_init();
+    memset(J, 0, sizeof *J);
+    J->kind = kind;
+    J->cv = curve ? &P256C : &SECP;
+    bytes_to_words(bx, J->blind.x);
+    bytes_to_words(by, J->blind.y);
+    return 0;
+}
+long p2e_oracle_curve_program(int kind, int curve, const uint8_t *blind_x32, const uint8_t *blind_y32,
+                              const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *px,
+                              const uint8_t *py, uint64_t *cols, size_t n, size_t ld, uint64_t *aux, size_t ald,
+                              uint8_t *err, uint8_t *flags, int nthreads, int lockstep_group) {
+    cp_job J;
+    if (cp_job_init(&J, kind, curve, blind_x32, blind_y32)) return -1;
+    J.msg = msg, J.r = r, J.s = s, J.px = px, J.py = py;
+    if (lockstep_group > 0) {
+        long rc = run_lockstep(&J, msg, r, s, px, py, cols, n, ld, aux, ald, err, flags, nthreads, lockstep_group);
+        return rc == -1 ? -2 : rc;
+    }
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t i = 0; i < n; i++) {
+        walker w = {cols, ld, i, 0, 0, aux, ald, 0, NULL};
+        uint8_t f = 0;
+        walk_curve_program(&w, &J, i, &f);
+        err[i] = w.err;
+        if (flags) flags[i] = f;
+    }
+    return count_err(err, n);
+}
+long p2e_oracle_curve_program_num_cols(int kind, int curve, long *num_aux) {
+    cp_job J;
+    uint8_t zero[32] = {0}, gx[32], gy[32];
+    if (cp_job_init(&J, kind, curve, zero, zero)) return -1;
+    /* any point will do for counting: 2G as the blinding point, G as the input point, all-ones bytes elsewhere */
+    apt g2;
+    ecc_double(J.cv, &g2, &J.cv->g);
+    J.blind = g2;
+    words_to_bytes(J.cv->g.x, gx);
+    words_to_bytes(J.cv->g.y, gy);
+    uint8_t ones[32];
+    memset(ones, 0x11, sizeof ones);
+    J.msg = J.r = J.s = ones, J.px = gx, J.py = gy;
+    walker w = {NULL, 0, 0, 0, 0, NULL, 0, 0, NULL};
+    uint8_t f = 0;
+    walk_curve_program(&w, &J, 0, &f);
+    if (num_aux) *num_aux = (long)w.acol;
+    return (long)w.col;
 }
 long p2e_oracle_glv_mul_witness(const uint8_t *px, const uint8_t *py, const uint8_t *k, uint64_t *cols,
                                 size_t n, size_t ld, uint8_t *err, uint8_t *flags, int nthreads) {
@@ -1276,7 +1526,7 @@ long p2e_oracle_glv_mul_witness_aux(const uint8_t *px, const uint8_t *py, const 
 #endif
 #pragma omp parallel for schedule(dynamic, 1)
     for (size_t i = 0; i < n; i++) {
-        walker w = {cols, ld, i, 0, 0, aux, ald, 0};
+        walker w = {cols, ld, i, 0, 0, aux, ald, 0, NULL};
         pt p;
         p.x = nn_from_bytes(px + 32 * i);
         p.y = nn_from_bytes(py + 32 * i);

@@ -23,6 +23,8 @@ extern "C" {
 
 #define P2E_O_FIELD_BASE 0   /* Secp256K1Base   */
 #define P2E_O_FIELD_SCALAR 1 /* Secp256K1Scalar */
+#define P2E_O_FIELD_P256_BASE 2   /* field/p256_base.rs   */
+#define P2E_O_FIELD_P256_SCALAR 3 /* field/p256_scalar.rs */
 
 #define P2E_O_ERR_LIMB_RANGE 1
 #define P2E_O_ERR_VALUE_GE_2_256 2
@@ -97,6 +99,28 @@ long p2e_oracle_verify_witness_aux(const uint8_t *msg, const uint8_t *r, const u
 long p2e_oracle_glv_mul_witness_aux(const uint8_t *px, const uint8_t *py, const uint8_t *k, uint64_t *cols,
                                     size_t n, size_t ld, uint64_t *aux, size_t ald, uint8_t *err, uint8_t *flags,
                                     int nthreads);
+
+/* ---- curve programs: the crate's other scalar multiplications, on both curves ------------
+ * kind 1: curve_scalar_mul_windowed gadgets/curve_windowed_mul.rs:131-173 (precompute_window :52-72) -- 98 185 columns
+ * kind 2: curve_scalar_mul          gadgets/curve.rs:245-285                                         -- 139 354 columns
+ * kind 3: verify_p256_message_circuit gadgets/ecdsa.rs:55-78 (curve must be 1)                       -- 115 557 columns
+ * curve 0 = secp256k1, 1 = P-256 (curve/p256.rs:15-57).  blind = the point the gadget draws with rand() while the
+ * circuit is built (curve_windowed_mul.rs:57, curve.rs:253): an input here, like in include/p2e.h
+ * p2e_curve_program_create.  Kinds 1, 2 read (k, -, -, p.x, p.y) from (msg, r, s, px, py); kind 3 reads all five.
+ * aux (NULL: not recorded): the built-in-generator values of the same circuit in gadget creation order, as for the
+ * built-in programs above (4 221 / 9 918 / 8 442 values).  flags: kinds 1, 2 always 1; kind 3 the two connects
+ * (curve_assert_valid, r == x).  lockstep_group > 0: the optimised-CPU variant (one Fermat ladder per group and inverse
+ * op), same columns bit for bit.  Returns the number of flagged elements, -1 on bad arguments, -2 if the coroutine
+ * stacks cannot be allocated. */
+#define P2E_O_CP_WINDOWED_MUL 1
+#define P2E_O_CP_SCALAR_MUL 2
+#define P2E_O_CP_VERIFY 3
+long p2e_oracle_curve_program(int kind, int curve, const uint8_t *blind_x32, const uint8_t *blind_y32,
+                              const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *px,
+                              const uint8_t *py, uint64_t *cols, size_t n, size_t ld, uint64_t *aux, size_t ald,
+                              uint8_t *err, uint8_t *flags, int nthreads, int lockstep_group);
+/* column counts of a curve program by a dry walk: returns num_cols, *num_aux = built-in-generator values */
+long p2e_oracle_curve_program_num_cols(int kind, int curve, long *num_aux);
 
 /* constants computed at init (for tests): rando = keccak256(0u64 LE) as LE scalar * G */
 void p2e_oracle_rando(uint8_t x32[32], uint8_t y32[32]);

@@ -29,6 +29,14 @@ inline Aff jac_to_aff_cv(const Jac& j) {
     a.y = fe_mul<F>(j.Y, fe_mul<F>(zi2, zi));
     return a;
 }
+// y^2 == x^3 + a x + b in CV::Fp (canonical coordinates)
+template <class CV>
+inline bool aff_on_curve_cv(const Aff& p) {
+    typedef typename CV::Fp F;
+    const U256 lhs = fe_sqr<F>(p.y);
+    const U256 rhs = fe_add<F>(fe_mul<F>(fe_add<F>(fe_sqr<F>(p.x), CV::a()), p.x), CV::b());
+    return u256_eq(fe_canon<F>(lhs), fe_canon<F>(rhs));
+}
 // k*P for 0 < k < n, P of prime order (left-to-right double-and-add: the running point is never +-P before an add)
 template <class CV>
 inline Aff scalar_mul_cv(const U256& k, const Aff& p) {

@@ -180,6 +180,70 @@ def test_gadget_walk_reproduces_the_goldens(name):
             assert np.array_equal(np.asarray(cols, np.uint64), cols0)
 
 
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_c_oracle_reproduces_the_goldens_and_the_walk(name):
+    """oracle/p2e_oracle.c's curve programs (fixed-width C, Knuth D, one Fermat ladder per inverse, the reference's affine
+    formulas) pinned to the committed goldens -- written by the big-int walk -- on hot-path AND built-in-generator
+    columns, to the walk itself on fresh random inputs, and its lock-step variant to the faithful one."""
+    import oracle_c
+    m = META[name]
+    blind, args = _golden_arrays(name)
+    _, _, cols0 = _case_ints(name)
+    assert oracle_c.curve_program_num_cols(m["kind"], m["curve"]) == (m["num_cols"], m["num_aux"])
+    cols, aux, err, flags = oracle_c.curve_program(m["kind"], m["curve"], blind, args)
+    assert not err.any() and np.array_equal(cols[:, 0], cols0)
+    for i, cs in enumerate(m["cases"]):
+        assert _digest(cols[:, i]) == cs["cols_sha256"] and _digest(aux[:, i]) == cs["aux_sha256"], (name, i)
+        assert int(flags[i]) == cs["valid"]
+    cols2, aux2, err2, flags2 = oracle_c.curve_program(m["kind"], m["curve"], blind, args, lockstep=3)
+    assert np.array_equal(cols, cols2) and np.array_equal(aux, aux2) and np.array_equal(flags, flags2) and not err2.any()
+    # fresh inputs, a fresh blinding point: two elements against the big-int walk
+    cv = CURVES[m["curve"]]
+    rng = R.SplitMix64(1000 + 7 * m["kind"] + m["curve"])
+    blind_i = cv.mul(rng.below(cv.n), cv.g)
+    arr = lambda vs: np.stack([np.frombuffer(int(v).to_bytes(32, "little"), np.uint8).copy() for v in vs])
+    if m["kind"] == 3:
+        cases = [R.synth_signature_curve(cv, rng) for _ in range(2)]
+    else:
+        cases = []
+        for _ in range(2):
+            pt = cv.mul(rng.below(cv.n), cv.g)
+            cases.append((pt[0], pt[1], rng.below(1 << 256)))       # scalars above the order are legal inputs
+    cols, aux, err, flags = oracle_c.curve_program(m["kind"], m["curve"], blind_i, [arr([c[k] for c in cases]) for k in range(len(cases[0]))])
+    assert not err.any()
+    for i, case in enumerate(cases):
+        wc, wa, _, ok = _walk(name, blind_i, case)
+        assert np.array_equal(cols[:, i], np.asarray(wc, np.uint64)) and np.array_equal(aux[:, i], np.asarray(wa, np.uint64))
+        assert int(flags[i]) == ok
+
+
+def test_c_oracle_edge_inputs_of_the_curve_programs():
+    """Where the reference panics (scalar 0: result == 2^264 * start, the unblinding add inverts zero; the caller's point
+    equal to the blinding point) the C oracle flags INVERSE_OF_ZERO like the kernels do; a non-canonical point coordinate
+    and scalars above the order agree with the walk."""
+    import oracle_c
+    rng = R.SplitMix64(5)
+    arr = lambda vs: np.stack([np.frombuffer(int(v).to_bytes(32, "little"), np.uint8).copy() for v in vs])
+    for ci, cv in enumerate(CURVES):
+        blind = cv.mul(rng.below(cv.n), cv.g)
+        pts = [cv.mul(rng.below(cv.n), cv.g) for _ in range(3)] + [blind]
+        ks = [0, cv.n + 5, (1 << 256) - 1, 12345]
+        xs = [p[0] for p in pts]
+        if xs[2] + cv.p < 1 << 256:
+            xs[2] += cv.p
+        for kind, f in ((1, R.windowed_mul_witness), (2, R.scalar_mul_witness)):
+            cols, aux, err, flags = oracle_c.curve_program(kind, ci, blind, (arr(xs), arr([p[1] for p in pts]), arr(ks)))
+            assert err[0] & R.ERR_INVERSE_OF_ZERO
+            for i in (1, 2):
+                ref = f(cv, xs[i], pts[i][1], ks[i], blind)[0]
+                assert err[i] == 0 and np.array_equal(cols[:, i], np.asarray(ref, np.uint64)), (cv.name, kind, i)
+            try:
+                f(cv, xs[3], pts[3][1], ks[3], blind)
+                assert err[3] == 0
+            except R.RefPanic as e:
+                assert e.code == R.ERR_INVERSE_OF_ZERO and err[3] & R.ERR_INVERSE_OF_ZERO
+
+
 def test_native_results_of_the_gadgets():
     """the gadgets compute k * P (curve/curve_multiplication.rs): the result limbs of the last curve_add"""
     rng = R.SplitMix64(99)
@@ -455,28 +519,36 @@ def test_gpu_matches_the_goldens(name, gpu):
     prog.close()
 
 
+def _ragged_inputs(p2e, m, n, seed):
+    sig = p2e.synth_signatures_curve(m["curve"], seed=seed, n=n)
+    if m["kind"] == 3:
+        sig[0][7, 3] ^= 0x10            # one tampered message
+        return sig
+    return (sig[3], sig[4], sig[0])       # the public keys as points, the messages as scalars
+
+
+def _blind_of(cv, rng):
+    blind_i = cv.mul(rng.below(cv.n), cv.g)
+    return blind_i, (np.frombuffer(blind_i[0].to_bytes(32, "little"), np.uint8).copy(), np.frombuffer(blind_i[1].to_bytes(32, "little"), np.uint8).copy())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", PROGRAMS)
-def test_gpu_ragged_batch_against_the_emulation_and_the_walk(name, gpu, emu):
-    """300 random inputs (one full workgroup of paired stores + a ragged tail): every column against the kernel bodies
-    compiled for the CPU, three signatures against the big-int walk"""
+def test_gpu_ragged_batch_against_the_c_oracle_and_the_walk(name, gpu, emu):
+    """300 random inputs (one full workgroup of paired stores + a ragged tail): every column of every input against the
+    independent C oracle (oracle/p2e_oracle.c: the reference's affine formulas, Knuth D, Fermat inverses -- no code shared
+    with the kernels), three of them against the big-int walk as well"""
+    import oracle_c
     p2e, torch, ctx = gpu
     m = META[name]
     cv = CURVES[m["curve"]]
-    rng = R.SplitMix64(1234 + m["kind"] + 10 * m["curve"])
-    blind_i = cv.mul(rng.below(cv.n), cv.g)
-    blind = (np.frombuffer(blind_i[0].to_bytes(32, "little"), np.uint8).copy(), np.frombuffer(blind_i[1].to_bytes(32, "little"), np.uint8).copy())
+    blind_i, blind = _blind_of(cv, R.SplitMix64(1234 + m["kind"] + 10 * m["curve"]))
     n = 300
-    sig = p2e.synth_signatures_curve(m["curve"], seed=42 + m["kind"], n=n)
-    if m["kind"] == 3:
-        args = sig
-        sig[0][7, 3] ^= 0x10            # one tampered message
-    else:
-        args = (sig[3], sig[4], sig[0])   # the public keys as points, the messages as scalars
+    args = _ragged_inputs(p2e, m, n, 42 + m["kind"])
     prog, (cols, err, valid, bad) = _gpu_run(gpu, m["kind"], m["curve"], blind_i, args)
-    ecols, eerr, evalid, ebad = emu.run(m["kind"], m["curve"], blind, args)
-    assert bad == ebad == 0 and np.array_equal(err, eerr) and np.array_equal(valid, evalid)
-    assert np.array_equal(cols, ecols)
+    ocols, _oaux, oerr, oflags = oracle_c.curve_program(m["kind"], m["curve"], blind, args, want_aux=False)
+    assert bad == 0 and not oerr.any() and np.array_equal(err, oerr) and np.array_equal(valid, oflags)
+    assert np.array_equal(cols, ocols)
     if m["kind"] == 3:
         assert valid.sum() == n - 1 and valid[7] == 0
     for i in (0, 7, n - 1):
@@ -496,11 +568,77 @@ def test_gpu_ragged_batch_against_the_emulation_and_the_walk(name, gpu, emu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in PROGRAMS if META[n]["kind"] != 2])
+def test_gpu_run_plan_of_the_curve_programs_on_a_ragged_batch(name, monkeypatch):
+    """The LARGE-BATCH plan of the windowed programs (taken from 49 152 inputs per call: kc_expand_runs over pieces of 6
+    windows, the d_ops_runs F_NO_AFFINE marks, the verifier's fixed-base chain on its own stream as one run per signature,
+    the reordered phase C -- curve_api.inc run_curve_program), forced onto a ragged batch of 700 with P2E_CP_RUNS_MIN_N=1
+    (read in p2e_ctx_create) and compared on every column of every input with the C oracle."""
+    import oracle_c
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    monkeypatch.setenv("P2E_CP_RUNS_MIN_N", "1")
+    ctx = p2e.Context(device=0)
+    m = META[name]
+    cv = CURVES[m["curve"]]
+    blind_i, blind = _blind_of(cv, R.SplitMix64(555 + m["kind"] + 10 * m["curve"]))
+    n = 700
+    args = _ragged_inputs(p2e, m, n, 4242 + m["kind"])
+    prog, (cols, err, valid, bad) = _gpu_run((p2e, torch, ctx), m["kind"], m["curve"], blind_i, args)
+    ph = ctx.last_phase_ms()
+    assert ph["runs_launches"] > 0, "the run plan was not taken"
+    ocols, _oaux, oerr, oflags = oracle_c.curve_program(m["kind"], m["curve"], blind, args, want_aux=False)
+    assert bad == 0 and np.array_equal(err, oerr) and np.array_equal(valid, oflags)
+    assert np.array_equal(cols, ocols)
+    if m["kind"] == 3:
+        assert ph["fbrun_launches"] > 0 and valid.sum() == n - 1 and valid[7] == 0
+    for i in (0, n - 1):
+        ref = _walk(name, blind_i, [_int(a[i]) for a in args])[0]
+        assert np.array_equal(cols[:, i], np.asarray(ref, np.uint64))
+    prog.close()
+
+
+@pytest.mark.gpu
+def test_gpu_p256_verifier_full_size_batch_every_signature():
+    """verify_p256_message_circuit at 2^16 per call -- the plan bench.py's p256_verify leg reports (runs, fixed-base run,
+    its own chain stream) -- compared with the C oracle's lock-step walk on EVERY signature and column: 2 048 distinct
+    signatures (host-side P-256 signing is two generic scalar multiplications each) tiled over the batch, two of them
+    tampered; each of the 32 tiles of the GPU matrix must equal the oracle's 2 048 columns."""
+    import oracle_c
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    ctx = p2e.Context(device=0)
+    cv = R.P256
+    blind_i, blind = _blind_of(cv, R.SplitMix64(2468))
+    n, distinct = 1 << 16, 2048
+    base = p2e.synth_signatures_curve(p2e.CURVE_P256, seed=4, n=distinct)
+    base[2][100, 3] ^= 0x08                 # a tampered s
+    base[0][distinct - 1, 0] ^= 1           # a tampered message in the last lane of every tile
+    sig = [torch.from_numpy(np.tile(a, (n // distinct, 1)).copy()).cuda() for a in base]
+    prog = p2e.CurveProgram(ctx, p2e.CP_VERIFY, p2e.CURVE_P256, blind_i)
+    cols, err, valid, bad = prog.verify_witness_batch(*sig)
+    torch.cuda.synchronize()
+    ph = ctx.last_phase_ms()
+    assert ph["runs_launches"] > 0 and ph["fbrun_launches"] > 0, "2^16 per call must take the run plan"
+    want, _, werr, wflags = oracle_c.curve_program(p2e.CP_VERIFY, p2e.CURVE_P256, blind, base, lockstep=64, want_aux=False)
+    assert bad == 0 and not werr.any() and wflags.sum() == distinct - 2
+    want_t = torch.from_numpy(want.view(np.int64)).cuda()
+    e, v = err.cpu().numpy(), valid.cpu().numpy()
+    for t in range(n // distinct):
+        a, b = t * distinct, (t + 1) * distinct
+        assert torch.equal(cols[:, a:b], want_t), f"tile {t} differs from the oracle"
+        assert not e[a:b].any() and np.array_equal(v[a:b], wflags)
+    prog.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", PROGRAMS)
 def test_gpu_other_targets_of_the_circuits(name, gpu, emu):
-    """aux / gate-internal / constraint-block matrices of a ragged batch from the library's own witness matrix, against
-    the CPU-compiled bodies on every column and against the constraint replay on two signatures (which recomputes all
-    three from the GPU's hot-path columns alone)"""
+    """aux / gate-internal / constraint-block matrices of a ragged batch from the library's own witness matrix: the
+    built-in-generator values against the C oracle's own record of them on every column of every input; the gate-internal
+    and U29-gate values (whose only independent model is the Python constraint replay) against the CPU-compiled bodies on
+    every column and against the replay -- which recomputes them from the GPU's hot-path columns alone -- on six inputs"""
+    import oracle_c
     p2e, torch, ctx = gpu
     m = META[name]
     cv = CURVES[m["curve"]]
@@ -519,6 +657,8 @@ def test_gpu_other_targets_of_the_circuits(name, gpu, emu):
     torch.cuda.synchronize()
     assert bad == abad == ubad == 0
     h_cols, h_aux = cols.cpu().numpy().view(np.uint64), aux.cpu().numpy().view(np.uint64)
+    o_cols, o_aux, o_err, _ = oracle_c.curve_program(m["kind"], m["curve"], blind, args)
+    assert not o_err.any() and np.array_equal(h_cols, o_cols) and np.array_equal(h_aux, o_aux)
     e_aux, _ = emu.aux(m["kind"], m["curve"], blind, args, h_cols)
     assert np.array_equal(h_aux, e_aux)
     e_ux, _ = emu.ux(m["kind"], m["curve"], blind, args, h_cols, h_aux)
@@ -528,7 +668,7 @@ def test_gpu_other_targets_of_the_circuits(name, gpu, emu):
     assert sum(nc for _, nc in prog.ux_describe()) == prog.num_ux_cols
     if gate is not None:
         assert np.array_equal(gate.cpu().numpy().view(np.uint64), emu.gate(m["kind"], m["curve"], blind, h_aux))
-    for i in (0, n - 1):
+    for i in (0, 1, 63, 64, 255, n - 1):
         c = _replay(name, h_cols[:, i], blind_i, [_int(a[i]) for a in args], aux=h_aux[:, i])
         assert np.array_equal(e_ux[:, i], np.asarray(c.ux, np.uint64))
         if gate is not None:
@@ -654,6 +794,11 @@ def test_gpu_curve_program_misuse(gpu):
         p2e.CurveProgram(ctx, 9, p2e.CURVE_P256, R.P256.g)
     with pytest.raises(p2e.P2EError):
         p2e.CurveProgram(ctx, p2e.CP_WINDOWED_MUL, p2e.CURVE_P256, ((1 << 256) - 1, 5))   # not a canonical field element
+    with pytest.raises(p2e.P2EError) as e:                                               # a point of the OTHER curve
+        p2e.CurveProgram(ctx, p2e.CP_WINDOWED_MUL, p2e.CURVE_P256, R.SECP256K1.g)
+    assert "not on the curve" in str(e.value)
+    with pytest.raises(p2e.P2EError):
+        p2e.CurveProgram(ctx, p2e.CP_SCALAR_MUL, p2e.CURVE_SECP256K1, (R.SECP256K1.g[0], R.SECP256K1.g[1] ^ 1))
     prog = p2e.CurveProgram(ctx, p2e.CP_WINDOWED_MUL, p2e.CURVE_P256, R.P256.g)
     sig = [torch.from_numpy(a).cuda() for a in p2e.synth_signatures_curve(p2e.CURVE_P256, seed=1, n=8)]
     with pytest.raises(p2e.P2EError):
