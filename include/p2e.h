@@ -91,6 +91,27 @@ size_t p2e_scratch_bytes(int program /*0 verify, 1 glv_mul*/, size_t n);
  * programs report their kc_* kernels in the same slots.  Returns the number written (<= 12). */
 int p2e_last_phase_ms(p2e_ctx *ctx, float *out, int cap);
 
+/* ---- column blocks of a fused call, as they become final (the assembly step) -------- */
+/* The reference fills a PartialWitness generator by generator; a batch consumer -- the RCCL exchange that assembles the
+ * columns of a sharded batch on every rank, a D2H copy, a prover that starts on finished columns -- need not wait for
+ * the whole call either.  Every fused entry point (p2e_ecdsa_verify_witness[_compact]_batch, p2e_glv_mul_witness
+ * [_compact]_batch, p2e_curve_mul_witness_batch, p2e_p256_verify_witness_batch) leaves behind, per launch that writes
+ * witness columns, the block of columns [first_col, first_col + num_cols) it completes and a HIP event recorded behind
+ * it.  Blocks are disjoint, cover all columns of the program, and are listed in the order the launches were issued
+ * (the scalar phase first, then the expansion of every schedule piece as its chain and inversion batch finish).  In
+ * the compact container block k is rows [narrow_before(first_col), narrow_before(first_col + num_cols)) of the narrow
+ * matrix and the same of the wide one (p2e_compact_layout is monotonic in the column index).
+ * p2e_segments_describe: returns the number of blocks of the LAST fused call issued on ctx (valid from the moment that
+ * call returns -- with P2E_CTX_ASYNC that is before anything has run -- until the next call on ctx).
+ * p2e_segment_stream_wait: `stream` (a hipStream_t of the same device) waits until block k is final; nothing blocks on
+ * the host.  p2e_segment_sync: the host blocks until block k is final.  Both return 0, or P2E_E_INVALID / P2E_E_HIP. */
+typedef struct p2e_segment_desc {
+    uint32_t first_col, num_cols;
+} p2e_segment_desc;
+long p2e_segments_describe(p2e_ctx *ctx, p2e_segment_desc *out, size_t cap);
+int p2e_segment_stream_wait(p2e_ctx *ctx, int segment, void *stream);
+int p2e_segment_sync(p2e_ctx *ctx, int segment);
+
 /* ---- single generators (one reference run_once body each) ----------------------------------------- */
 /* MulNonnativeGenerator::run_once gates/mul_nonnative.rs:249-324 followed by
  * CheckSumGenerator::run_once :513-531.  x, y: the gate's 9+9 input wires.  Outputs in gate wire

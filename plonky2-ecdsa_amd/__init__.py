@@ -54,6 +54,7 @@ WINDOWED_MUL_COLS, SCALAR_MUL_COLS, P256_VERIFY_COLS = 98185, 139354, 115557
 # every symbol include/p2e.h declares
 EXPORTS = (
     "p2e_ctx_create", "p2e_ctx_destroy", "p2e_sync", "p2e_last_error", "p2e_scratch_bytes", "p2e_last_phase_ms",
+    "p2e_segments_describe", "p2e_segment_stream_wait", "p2e_segment_sync",
     "p2e_mul_witness_batch", "p2e_checksum_witness_batch", "p2e_add_witness_batch", "p2e_sub_witness_batch",
     "p2e_add_many_witness_batch", "p2e_inv_witness_batch", "p2e_glv_decompose_batch", "p2e_limb_split",
     "p2e_limb_pack", "p2e_ecdsa_verify_witness_batch", "p2e_glv_mul_witness_batch", "p2e_columns_to_rows",
@@ -75,19 +76,36 @@ class P2EError(RuntimeError):
     pass
 
 
-def build(verbose: bool = False) -> str:
-    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+def build(verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU).  csrc/p2e_hip.hip is ONE source
+    compiled as four translation units side by side (-DP2E_PART=0..3, see the top of the file) and linked into
+    libp2e_hip.so.  ``extra_flags`` / ``out``: experimental builds for tools/ (never the product library)."""
+    from concurrent.futures import ThreadPoolExecutor
     src = os.path.join(_HERE, "csrc", "p2e_hip.hip")
+    lib_path = out or LIB_PATH
     deps = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
     deps.append(os.path.join(_ROOT, "include", "p2e.h"))
-    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp",
-           "-o", LIB_PATH, src]
+    if not extra_flags and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(d) for d in deps):
+        return lib_path
+    objdir = os.path.join(_HERE, "build", os.path.basename(lib_path))
+    os.makedirs(objdir, exist_ok=True)
+    common = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fopenmp", *extra_flags]
+
+    def compile_part(part):
+        obj = os.path.join(objdir, f"part{part}.o")
+        cmd = common + [f"-DP2E_PART={part}", "-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_part, range(4)))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-o", lib_path, *objs]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 _lib = None
@@ -505,6 +523,26 @@ class Context:
         self._L.p2e_last_phase_ms(self._h, buf, C.c_int(12))
         return dict(zip(("scalar", "expand_launches", "expand_cols", "expand", "total", "runs_launches", "runs_cols",
                          "runs", "fbrun_launches", "fbrun_cols", "fbrun"), [float(x) for x in buf]))
+
+    # ---- column blocks of the last fused call, as they become final (include/p2e.h p2e_segments_describe) -------------
+    def segments(self):
+        """[(first_col, num_cols)] of the last fused call issued on this context, in issue order: the scalar phase's
+        blocks, then one block per expansion launch.  Disjoint; together every column of the program."""
+        self._L.p2e_segments_describe.restype = C.c_long
+        k = self._L.p2e_segments_describe(self._h, None, C.c_size_t(0))
+        buf = (C.c_uint32 * (2 * max(k, 1)))()
+        self._L.p2e_segments_describe(self._h, buf, C.c_size_t(k))
+        return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(k)]
+
+    def segment_stream_wait(self, k: int, stream: int):
+        """`stream` (a raw hipStream_t handle, e.g. torch.cuda.Stream().cuda_stream) waits until block k is final."""
+        if self._L.p2e_segment_stream_wait(self._h, C.c_int(k), C.c_void_p(stream)) != 0:
+            raise P2EError(self._L.p2e_last_error().decode())
+
+    def segment_sync(self, k: int):
+        """the host blocks until block k is final"""
+        if self._L.p2e_segment_sync(self._h, C.c_int(k)) != 0:
+            raise P2EError(self._L.p2e_last_error().decode())
 
     # ---- allocation helpers -------------------------------------------------------------------------
     def _cols(self, k, n):

@@ -21,6 +21,16 @@
 
 using namespace p2e;
 
+// The library is ONE source compiled as four translation units in parallel (plonky2_ecdsa_amd.build: -DP2E_PART=0..3),
+// because a single hipcc job over all kernels takes five minutes:  0 = context, single generators, layout helpers,
+// streaming passes, descriptions;  1 = the fused pipeline of the two built-in programs (run_program);  2 / 3 = the
+// curve-program pipeline instantiated for secp256k1 / P-256 (run_curve_program<CV>).  Undefined = everything in one
+// unit.  Small static helpers (error text, staging, scratch) are compiled into every part.
+#ifndef P2E_PART
+#define P2E_PART (-1)
+#endif
+#define P2E_HAS(p) (P2E_PART < 0 || P2E_PART == (p))
+
 // ====================================================================================================
 // kernels
 // ====================================================================================================
@@ -46,6 +56,7 @@ template <> struct EmitOf<1> { typedef PairEmit type; };
 template <> struct EmitOf<2> { typedef CompactEmit type; };
 template <> struct EmitOf<3> { typedef CompactPairEmit type; };
 template <> struct EmitOf<4> { typedef NullEmit type; };   // no witness: p2e_ecdsa_verify_batch
+#if P2E_HAS(1)
 template <int MODE>
 __global__ __launch_bounds__(BS) void k_scalar(Program G, Buffers B, size_t first) {
     size_t i = lane_sig<(MODE & 1) != 0>(first);
@@ -142,6 +153,7 @@ __global__ __launch_bounds__(BS) void k_verify_check(Program G, Buffers B) {
     size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
     if (i < B.n) body_verify_check(G, B, i);
 }
+#endif   // P2E_HAS(1)
 // built-in-generator columns from the finished witness matrix: one (signature, item) per lane (aux.hpp)
 // MODE bit 0 = paired stores over full workgroups, bit 1 = u32 output matrix
 template <int MODE> struct AuxEmitOf;
@@ -149,6 +161,7 @@ template <> struct AuxEmitOf<0> { typedef Emit type; };
 template <> struct AuxEmitOf<1> { typedef PairEmit type; };
 template <> struct AuxEmitOf<2> { typedef Emit32 type; };
 template <> struct AuxEmitOf<3> { typedef PairEmit32 type; };
+#if P2E_HAS(0)
 template <int MODE>
 __global__ __launch_bounds__(BS) void k_aux(AuxArgs A, size_t first) {
     size_t i = lane_sig<(MODE & 1) != 0>(first);
@@ -167,8 +180,9 @@ __global__ __launch_bounds__(BS) void k_ux(UxArgs A, size_t first) {
     size_t i = lane_sig<(MODE & 1) != 0>(first);
     if ((MODE & 1) || i < A.n) body_ux<typename AuxEmitOf<MODE>::type>(A, (int)blockIdx.y, i);
 }
-// err words -> caller's err bytes, valid bytes, flagged count
-__global__ __launch_bounds__(BS) void k_finalize(const u32* err32, const uint8_t* valid8, uint8_t* err_out,
+#endif   // P2E_HAS(0)
+// err words -> caller's err bytes, valid bytes, flagged count (every part launches it: internal linkage)
+static __global__ __launch_bounds__(BS) void k_finalize(const u32* err32, const uint8_t* valid8, uint8_t* err_out,
                                                  uint8_t* valid_out, size_t n, unsigned long long* counter) {
     size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
     bool bad = false;
@@ -182,6 +196,7 @@ __global__ __launch_bounds__(BS) void k_finalize(const u32* err32, const uint8_t
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (unsigned long long)__popcll(m));
 }
 
+#if P2E_HAS(0)
 __device__ __forceinline__ void count_err(uint8_t e, unsigned long long* counter) {
     unsigned long long m = __ballot(e != 0);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (unsigned long long)__popcll(m));
@@ -430,11 +445,16 @@ __global__ __launch_bounds__(BS) void k_compact(const u64* __restrict__ cols, si
     if (bad_a) atomicOr(&err32[i], (u32)ERR_LIMB_RANGE);
     if (bad_b) atomicOr(&err32[i + 1], (u32)ERR_LIMB_RANGE);
 }
+#endif   // P2E_HAS(0)
 
 // ====================================================================================================
 // context
 // ====================================================================================================
-static thread_local std::string g_last_error;
+#if P2E_HAS(0)
+thread_local std::string g_last_error;
+#else
+extern thread_local std::string g_last_error;
+#endif
 static void set_error(const std::string& s) { g_last_error = s; }
 #define HIP_TRY(expr)                                                                        \
     do {                                                                                     \
@@ -511,6 +531,13 @@ struct p2e_ctx {
     int n_expand = 0, n_seg = 0;
     double expand_cols[MAX_EXPAND] = {};
     int expand_kind[MAX_EXPAND] = {};
+    // column blocks of the last fused call in issue order (p2e_segments_describe): ev < 0 = the scalar phase (ev[1]),
+    // otherwise the block is final when ev_c1[ev] has completed
+    struct SegBlock {
+        u32 col0, ncols;
+        int ev;
+    };
+    std::vector<SegBlock> seg_blocks;
     int msm_pieces = 8, fixed_pieces = 2;   // one Montgomery inversion batch per piece
     int msm_pieces_small = 5, fixed_pieces_small = 1;   // ... of the small-batch plan (fewer launches and inversions)
     int run_iters = 9;                      // MSM-loop iterations per expansion run (0: expand op by op)
@@ -562,6 +589,7 @@ struct p2e_ctx {
     bool have_phases = false;
 };
 
+#if P2E_HAS(0)
 // wide = the 33 check_sum / carry columns of every mul generator (Goldilocks residues of signed sums, carries offset
 // by 2^33: gates/mul_nonnative.rs:305-322,518-527); everything else on the path is < 2^32 by construction
 static void build_compact_map(DeviceProgram& P) {
@@ -619,6 +647,7 @@ static std::vector<OpDesc> host_ops(int program, int run_iters, bool fb_run = tr
     b.mark_runs(run_iters, fb_run);
     return b.ops;
 }
+#endif   // P2E_HAS(0)
 
 struct ScratchLayout {
     size_t px, py, pz, pw, pref, ax, ay, dig4, dig2, msrc, dyn, src, err32, valid8, total;
@@ -650,6 +679,7 @@ static ScratchLayout scratch_layout(const Program& G, size_t n) {
     return L;
 }
 
+#if P2E_HAS(0)
 extern "C" const char* p2e_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" size_t p2e_scratch_bytes(int program, size_t n) {
@@ -914,6 +944,68 @@ extern "C" int p2e_last_phase_ms(p2e_ctx* c, float* out, int cap) {
     return k;
 }
 
+extern "C" long p2e_segments_describe(p2e_ctx* c, p2e_segment_desc* out, size_t cap) {
+    if (!c) return P2E_E_INVALID;
+    for (size_t k = 0; out && k < c->seg_blocks.size() && k < cap; k++) {
+        out[k].first_col = c->seg_blocks[k].col0;
+        out[k].num_cols = c->seg_blocks[k].ncols;
+    }
+    return (long)c->seg_blocks.size();
+}
+static hipEvent_t segment_event(p2e_ctx* c, int k) {
+    if (!c || k < 0 || (size_t)k >= c->seg_blocks.size()) return nullptr;
+    const int e = c->seg_blocks[(size_t)k].ev;
+    return e < 0 ? c->ev[1] : c->ev_c1[e];
+}
+extern "C" int p2e_segment_stream_wait(p2e_ctx* c, int k, void* stream) {
+    hipEvent_t ev = segment_event(c, k);
+    if (!ev) {
+        set_error("no such segment (p2e_segments_describe of the last fused call)");
+        return P2E_E_INVALID;
+    }
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ev, 0));
+    return 0;
+}
+extern "C" int p2e_segment_sync(p2e_ctx* c, int k) {
+    hipEvent_t ev = segment_event(c, k);
+    if (!ev) {
+        set_error("no such segment (p2e_segments_describe of the last fused call)");
+        return P2E_E_INVALID;
+    }
+    DeviceGuard guard(c->device);
+    HIP_TRY(hipEventSynchronize(ev));
+    return 0;
+}
+#endif   // P2E_HAS(0)
+
+// ---- column blocks of a fused call (p2e_segments_describe) -------------------------------------------
+static inline u32 op_cols(const OpDesc& op) { return op.kind == OP_DBL ? COLS_DBL : op.kind == OP_CADD ? COLS_CADD : COLS_ADD; }
+// the scalar phase writes every column that no curve op owns: the complement of the ops' column ranges
+static void seg_begin_call(p2e_ctx* c, const std::vector<OpDesc>& h_ops, u32 num_cols) {
+    c->seg_blocks.clear();
+    std::vector<std::pair<u32, u32>> r;
+    r.reserve(h_ops.size());
+    for (const OpDesc& op : h_ops) r.push_back({op.col, op.col + op_cols(op)});
+    std::sort(r.begin(), r.end());
+    u32 at = 0;
+    for (const auto& x : r) {
+        if (x.first > at) c->seg_blocks.push_back({at, x.first - at, -1});
+        at = std::max(at, x.second);
+    }
+    if (at < num_cols) c->seg_blocks.push_back({at, num_cols - at, -1});
+}
+// expansion launch e (event pair ev_c0[e] / ev_c1[e]) completes the columns of ops [lo, hi) (consecutive ops of one chain
+// are consecutive generators: one contiguous block)
+static void seg_note_expand(p2e_ctx* c, int e, const std::vector<OpDesc>& h_ops, int lo, int hi) {
+    u32 c0 = 0xFFFFFFFFu, c1 = 0;
+    for (int t = lo; t < hi; t++) {
+        c0 = std::min(c0, h_ops[t].col);
+        c1 = std::max(c1, h_ops[t].col + op_cols(h_ops[t]));
+    }
+    if (hi > lo) c->seg_blocks.push_back({c0, c1 - c0, e});
+}
+
 static int ensure_scratch(p2e_ctx* c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return 0;
     if (c->scratch) {
@@ -1047,6 +1139,7 @@ static inline dim3 grid1(size_t n) { return dim3((unsigned)((n + BS - 1) / BS));
 // ====================================================================================================
 // single generators
 // ====================================================================================================
+#if P2E_HAS(0)
 extern "C" long p2e_mul_witness_batch(p2e_ctx* c, int field, const uint64_t* x, const uint64_t* y, uint64_t* r,
                                       uint64_t* q, uint64_t* cs, uint64_t* b, size_t n, size_t ld, uint8_t* err) {
     if (bad_common(c, n, ld) || !x || !y || !r || !q || !cs || !b || !err || (field < 0 || field > 3)) return P2E_E_INVALID;
@@ -1216,10 +1309,12 @@ extern "C" long p2e_limb_pack(p2e_ctx* c, const uint64_t* limbs, uint8_t* packed
     hipLaunchKernelGGL(k_pack, grid1(n), dim3(BS), 0, c->stream, limbs, packed, n, ld, err, c->d_counter);
     return S.done(finish_call(c));
 }
+#endif   // P2E_HAS(0)
 
 // ====================================================================================================
 // fused schedules
 // ====================================================================================================
+#if P2E_HAS(1)
 // cols != nullptr: the u64 column matrix; otherwise the compact container (narrow, wide)
 static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8_t* r, const uint8_t* s,
                         const uint8_t* pkx, const uint8_t* pky, uint64_t* cols, size_t n, size_t ld, uint8_t* err,
@@ -1279,6 +1374,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     ZERO_COUNTER(c);
     unsigned gx = (unsigned)((n + BS - 1) / BS);
     c->n_expand = 0;
+    c->seg_blocks.clear();
     if (verify_only) {
         // the native verification alone: scalar phase without emission, the two chains side by side in Jacobian
         // coordinates (no batch inversion, no expansion), the final add, r == x on its Jacobian result
@@ -1407,6 +1503,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         else
             hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, st, G, B, lo, hi, have_prefix);
     };
+    seg_begin_call(c, DP.h_ops, (u32)G.num_cols);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (gx_wide) LAUNCH_EMIT(k_scalar, true, dim3(gx_wide), c->stream, G, B, (size_t)0);
     if (gx_tail) LAUNCH_EMIT(k_scalar, false, dim3(gx_tail), c->stream, G, B, n_wide);
@@ -1511,6 +1608,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 1;
             c->expand_cols[e] = cols_of(G.msm_loop_begin + 3 * sg.it0, G.msm_loop_begin + 3 * sg.it1);
+            seg_note_expand(c, e, DP.h_ops, G.msm_loop_begin + 3 * sg.it0, G.msm_loop_begin + 3 * sg.it1);
         }
         if (sg.fb_run) {
             const int e = c->n_expand++;
@@ -1520,6 +1618,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 2;
             c->expand_cols[e] = cols_of(G.fb_begin, G.fb_begin + G.fb_windows);
+            seg_note_expand(c, e, DP.h_ops, G.fb_begin, G.fb_begin + G.fb_windows);
         }
         if (sg.s_hi > sg.s_lo) {
             const int e = c->n_expand++;
@@ -1529,6 +1628,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 0;
             c->expand_cols[e] = cols_of(sg.s_lo, sg.s_hi);
+            seg_note_expand(c, e, DP.h_ops, sg.s_lo, sg.s_hi);
         }
     }
     if (used_c2) {   // join the second expansion stream
@@ -1577,7 +1677,9 @@ extern "C" long p2e_glv_mul_witness_compact_batch(p2e_ctx* c, const uint8_t* px3
     if (n == 0) return 0;
     return run_program(c, 1, k32, k32, k32, px32, py32, nullptr, n, 0, err, valid, narrow, ld_narrow, wide, ld_wide);
 }
+#endif   // P2E_HAS(1)
 
+#if P2E_HAS(0)
 extern "C" long p2e_columns_to_rows(p2e_ctx* c, const uint64_t* cols, size_t ld, size_t n, size_t ncols,
                                     uint64_t* rows, size_t row_ld) {
     if (bad_common(c, n, ld) || !cols || !rows || row_ld < ncols) return P2E_E_INVALID;
@@ -1998,5 +2100,6 @@ extern "C" int p2e_synth_signatures(uint64_t seed, size_t first, size_t n, uint8
     }
     return 0;
 }
+#endif   // P2E_HAS(0)
 
 #include "curve_api.inc"

@@ -48,6 +48,14 @@ pub struct P2eWireMapEntry {
     pub dst: u32, // wire * degree + row
 }
 
+/// a block of witness columns completed by one launch of a fused call (include/p2e.h p2e_segments_describe)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct P2eSegmentDesc {
+    pub first_col: u32,
+    pub num_cols: u32,
+}
+
 pub const P2E_CTX_HOST_POINTERS: u32 = 1;
 pub const P2E_CTX_ASYNC: u32 = 2;
 pub const P2E_VERIFY_COLS: usize = 82_615;
@@ -85,6 +93,10 @@ extern "C" {
     pub fn p2e_scratch_bytes(program: i32, n: usize) -> usize;
     // per-phase / per-kernel HIP-event timings of the last fused call on this context (bench.py's roofline figures)
     pub fn p2e_last_phase_ms(ctx: *mut P2eCtx, out: *mut f32, cap: i32) -> i32;
+    // column blocks of the last fused call as they become final: what an RCCL exchange / D2H copy / prover can start on
+    pub fn p2e_segments_describe(ctx: *mut P2eCtx, out: *mut P2eSegmentDesc, cap: usize) -> i64;
+    pub fn p2e_segment_stream_wait(ctx: *mut P2eCtx, segment: i32, stream: *mut c_void) -> i32;
+    pub fn p2e_segment_sync(ctx: *mut P2eCtx, segment: i32) -> i32;
 
     // ---- the fused schedules: every hot-path run_once of one circuit instance per batch element
     // gadgets/ecdsa.rs:30-53 (gates/mul_nonnative.rs:249-324,513-531; gadgets/nonnative.rs:626-645,696-728,792-810,

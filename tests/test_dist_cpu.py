@@ -73,6 +73,70 @@ def _worker(rank, world, port, total, q):
         for c in (0, 17, 18, 50, 344, 17141, 50000, 82614):     # limbs, check_sum and carry columns
             got = pd.global_column_compact(gn, gw, cmap, c, total).numpy().view(np.uint64)
             ok = ok and np.array_equal(got, want[c])
+    # ---- the assembly pipelined with the fill (ColumnAssembly / assemble_fill): blocks of columns exchanged in the order a
+    # producer completes them, straight into the final (world, cols, ld) layout.  The producer here is a stand-in for an
+    # asynchronous p2e.Context: block k of the staged shard only holds its values once segment_sync(k) has been called
+    # (poison before), and the blocks complete out of column order, as the launch plans' do.
+    class FakeCtx:
+        def __init__(self, finished, stage, blocks):
+            self.finished, self.stage, self.blocks, self.synced = finished, stage, blocks, []
+
+        def segments(self):
+            return list(self.blocks)
+
+        def segment_sync(self, k):
+            c0, nc = self.blocks[k]
+            self.stage[c0:c0 + nc] = self.finished[c0:c0 + nc]
+            self.synced.append(k)
+
+    cuts = [0, 344, 17141, 17345, 30000, 30001, 61000, p2e.VERIFY_COLS]
+    blocks = [(cuts[i], cuts[i + 1] - cuts[i]) for i in (0, 2, 5, 1, 4, 3, 6)]       # issue order != column order
+    n_max = -(-total // world)
+    ld = n_max + 2
+    asm = pd.ColumnAssembly([torch.full((world, p2e.VERIFY_COLS, ld), -7, dtype=torch.int64)], total)
+    stage = torch.full((p2e.VERIFY_COLS, ld), -9, dtype=torch.int64)
+    finished = torch.full((p2e.VERIFY_COLS, ld), -9, dtype=torch.int64)
+    finished[:, :n_local] = local
+    fake = FakeCtx(finished, stage, blocks)
+    segs = pd.assemble_fill(fake, asm, issue=lambda: None, host_stage=[stage])
+    ok = ok and segs == blocks and sorted(fake.synced) == list(range(len(blocks)))
+    got_all = asm.matrices[0]
+    for r in range(world):
+        s_, e_ = pd.shard_bounds(total, r, world)
+        ok = ok and torch.equal(got_all[r, :, :e_ - s_], gathered[r, :, :e_ - s_])
+        if e_ - s_ < n_max:
+            ok = ok and bool((gathered[r, :, e_ - s_:n_max] == 0).all())        # all_gather_columns: the pad column is zero
+    if rank == 0:
+        for c in (0, 343, 344, 17141, 30000, 82614):
+            ok = ok and np.array_equal(asm.global_column(c).numpy().view(np.uint64), want[c])
+    # ranks that disagree on the block list (shards straddling a launch-plan threshold): one block behind the last event
+    asm2 = pd.ColumnAssembly([torch.full((world, p2e.VERIFY_COLS, ld), -7, dtype=torch.int64)], total)
+    stage2 = torch.full((p2e.VERIFY_COLS, ld), -9, dtype=torch.int64)
+    fake2 = FakeCtx(finished, stage2, blocks if rank == 0 else [(0, 17141), (17141, p2e.VERIFY_COLS - 17141)])
+    pd.assemble_fill(fake2, asm2, issue=lambda: None, host_stage=[stage2])
+    for r in range(world):
+        s_, e_ = pd.shard_bounds(total, r, world)
+        ok = ok and torch.equal(asm2.matrices[0][r, :, :e_ - s_], gathered[r, :, :e_ - s_])
+    # the compact container through the same path: a block of columns is a block of rows of each matrix
+    asm3 = pd.ColumnAssembly([torch.full((world, nn, ld), -7, dtype=torch.int32), torch.full((world, nw, ld), -7, dtype=torch.int64)], total)
+    st_n, st_w = torch.full((nn, ld), -9, dtype=torch.int32), torch.full((nw, ld), -9, dtype=torch.int64)
+    fin_n, fin_w = st_n.clone(), st_w.clone()
+    fin_n[:, :n_local] = torch.from_numpy(narrow.view(np.int32))
+    fin_w[:, :n_local] = torch.from_numpy(wide.view(np.int64))
+    nar_r, wid_r = pd.compact_row_ranges(cmap, blocks)
+
+    class FakeCompact(FakeCtx):
+        def segment_sync(self, k):
+            (a, na), (b, nb) = nar_r[k], wid_r[k]
+            st_n[a:a + na] = fin_n[a:a + na]
+            st_w[b:b + nb] = fin_w[b:b + nb]
+
+    pd.assemble_fill(FakeCompact(None, None, blocks), asm3, issue=lambda: None, compact_map=cmap, host_stage=[st_n, st_w])
+    ok = ok and sum(x[1] for x in nar_r) == nn and sum(x[1] for x in wid_r) == nw
+    if rank == 0:
+        for c in (0, 17, 18, 50, 344, 17141, 50000, 82614):
+            got = pd.global_column_compact(asm3.matrices[0][:, :, :n_max], asm3.matrices[1][:, :, :n_max], cmap, c, total).numpy().view(np.uint64)
+            ok = ok and np.array_equal(got, want[c])
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, bool(ok)))

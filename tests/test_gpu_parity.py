@@ -796,3 +796,69 @@ def test_assemble_wires_against_numpy():
     hctx = p2e.Context(device=0, host_pointers=True)
     hw = hctx.assemble_wires(hctx.wire_map(0, rsrc, rdst, 64, cells // 64), hc[:, :5].copy(), ha[:, :5].copy(), hu[:, :5].copy())
     assert np.array_equal(np.asarray(hw)[:, named], want[:5][:, named].view(np.uint64))
+
+
+@pytest.mark.parametrize("plan", ["four_lanes", "lane_per_signature_runs"])
+def test_column_blocks_are_final_when_their_event_fires(monkeypatch, plan):
+    """include/p2e.h p2e_segments_describe / p2e_segment_stream_wait (what the pipelined assembly of a
+    sharded batch stands on).  The blocks of an ASYNCHRONOUS fill must be disjoint, cover every column, and block k must
+    hold its final values as soon as its event has fired: a copy stream waits for each block's event and copies the block
+    out of the (poisoned) output while the later launches are still running; the copies together must be the oracle's
+    matrix.  Both containers; the four-lane plan (two expansion streams) and the run plan."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    if plan == "lane_per_signature_runs":
+        monkeypatch.setenv("P2E_QUAD_MAX_N", "0")
+        monkeypatch.setenv("P2E_RUNS_MIN_N", "0")
+    n = 3000 + 77
+    sigs = p2e.synth_signatures(seed=91, n=n)
+    want, _, _ = oracle_c.verify_witness_lockstep(*sigs)
+    want_t = torch.from_numpy(want.view(np.int64)).cuda()
+    work, copy = torch.cuda.Stream(), torch.cuda.Stream()
+    ctx = p2e.Context(device=0, stream=work.cuda_stream, asynchronous=True)
+    dev = [torch.from_numpy(a).cuda() for a in sigs]
+    cols = torch.full((p2e.VERIFY_COLS, n + 1), -1, dtype=torch.int64, device="cuda")
+    snap = torch.full((p2e.VERIFY_COLS, n), -2, dtype=torch.int64, device="cuda")
+    err = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    valid = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.ecdsa_verify_witness_batch(*dev, cols=cols[:, :n], err=err, valid=valid, ld=n + 1)
+    segs = ctx.segments()
+    covered = np.zeros(p2e.VERIFY_COLS, dtype=np.int32)
+    with torch.cuda.stream(copy):
+        for k, (c0, nc) in enumerate(segs):
+            covered[c0:c0 + nc] += 1
+            ctx.segment_stream_wait(k, copy.cuda_stream)
+            snap[c0:c0 + nc].copy_(cols[c0:c0 + nc, :n], non_blocking=True)
+    assert (covered == 1).all() and len(segs) >= 6
+    copy.synchronize()
+    assert ctx.sync() == 0
+    assert torch.equal(snap, want_t) and torch.equal(cols[:, :n], want_t) and bool((cols[:, n] == -1).all())
+    # the host-blocking form, and the compact container (a block of columns = a block of rows of each matrix)
+    from plonky2_ecdsa_amd.dist import compact_row_ranges
+    cmap, nn, nw = p2e.compact_layout(0)
+    nar = torch.full((nn, n + 1), -1, dtype=torch.int32, device="cuda")
+    wid = torch.full((nw, n + 1), -1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.ecdsa_verify_witness_compact_batch(*dev, narrow=nar[:, :n], wide=wid[:, :n], err=err, valid=valid, ld_narrow=n + 1, ld_wide=n + 1)
+    segs2 = ctx.segments()
+    nr, wr = compact_row_ranges(cmap, segs2)
+    got_n, got_w = [], []
+    for k in range(len(segs2)):
+        ctx.segment_sync(k)
+        with torch.cuda.stream(copy):
+            got_n.append((nr[k], nar[nr[k][0]:nr[k][0] + nr[k][1], :n].clone()))
+            got_w.append((wr[k], wid[wr[k][0]:wr[k][0] + wr[k][1], :n].clone()))
+    copy.synchronize()
+    assert ctx.sync() == 0
+    is_wide = (cmap & p2e.COMPACT_WIDE) != 0
+    want_n = (want_t[torch.from_numpy(np.nonzero(~is_wide)[0]).cuda()])
+    want_w = want_t[torch.from_numpy(np.nonzero(is_wide)[0]).cuda()]
+    for (r0, k_), blk in got_n:
+        assert torch.equal(blk.to(torch.int64) & 0xFFFFFFFF, want_n[r0:r0 + k_])
+    for (r0, k_), blk in got_w:
+        assert torch.equal(blk, want_w[r0:r0 + k_])
+    assert sum(k_ for (_, k_), _ in got_n) == nn and sum(k_ for (_, k_), _ in got_w) == nw
+    with pytest.raises(p2e.P2EError):
+        ctx.segment_sync(len(segs2))
+    ctx.close()

@@ -13,7 +13,7 @@
 #   timeline:P        rocprofv3 kernel timeline of one 2^16 step with P MSM pieces (tools/trace_timeline.sh)
 #   py:SCRIPT[:ARGS]  python tools/SCRIPT ARGS
 #   env:NAME=VALUE    export for the jobs that follow
-#   strong:N          bench.py --scaling strong with N gloo ranks sharing the one GPU (rehearsal of the N>1 code path)
+#   ranks:N[:ARGS]    bench.py ARGS on N gloo ranks sharing the one GPU (rehearsal of the N>1 code paths)
 set -u
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -40,7 +40,9 @@ for job in "$@"; do
     timeline) run "timeline_$arg" 400 tools/trace_timeline.sh "$arg" 2 || exit 1 ;;
     py)       script=${arg%%:*}; sargs=""; [[ "$arg" == *:* ]] && sargs=${arg#*:}
               run "py_${script%.py}${sargs:+_}${sargs//[^A-Za-z0-9_]/_}" 1100 python "tools/$script" ${sargs//+/ } || exit 1 ;;
-    strong)   run "strong_$arg" 900 env P2E_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node "$arg" --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus "$arg" --scaling strong --steps 5 --warmup 2 --no-cpu-baseline --no-limb-split --no-p256 || exit 1 ;;
+    ranks)    # ranks:N[:ARGS]  bench.py on N gloo ranks sharing the one GPU (rehearsal of the N>1 code paths; ARGS as for bench)
+              nr=${arg%%:*}; rargs=""; [[ "$arg" == *:* ]] && rargs=${arg#*:}
+              run "ranks_${nr}${rargs:+_}${rargs//[^A-Za-z0-9_]/_}" 900 env P2E_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node "$nr" --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus "$nr" --steps 4 --warmup 1 --check 64 ${rargs//+/ } || exit 1 ;;
     *)        echo "unknown job $job"; exit 2 ;;
     esac
 done
