@@ -197,6 +197,8 @@ static __global__ __launch_bounds__(BS) void k_finalize(const u32* err32, const 
 }
 
 #if P2E_HAS(0)
+// one empty wave: makes the runtime bind a hardware queue to a stream NOW (p2e_ctx_create), see there
+__global__ void k_touch() {}
 __device__ __forceinline__ void count_err(uint8_t e, unsigned long long* counter) {
     unsigned long long m = __ballot(e != 0);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (unsigned long long)__popcll(m));
@@ -826,6 +828,23 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     for (auto& e : c->ev_piece) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_c0) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->ev_c1) HIP_TRY(hipEventCreate(&e));
+    // HIP binds a hardware queue to a stream at the stream's FIRST launch, not at its creation, and hands the queues out
+    // in that order; which queues end up as neighbours on a hardware pipe depends on it.  Measured in round 2: the step
+    // time of the small and mid-size plans moved by +-10...20 % with whether the caller's first GPU work came before or
+    // after this context's.  So the order is fixed HERE, once, the same for every caller: the
+    // legacy default stream first (a caller that has not touched the GPU yet gets its queue now instead of in the middle
+    // of ours), then the context's streams in the order below.  P2E_TOUCH_STREAMS=0 restores the lazy binding.
+    {
+        const char* env = getenv("P2E_TOUCH_STREAMS");
+        if (!env || atoi(env) != 0) {
+            hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, (hipStream_t)0);
+            HIP_TRY(hipStreamSynchronize((hipStream_t)0));
+            for (hipStream_t st : {c->stream, c->st_msm, c->st_fixed, c->st_binv, c->st_c2}) {
+                hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, st);
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+        }
+    }
     if (const char* env = getenv("P2E_MSM_PIECES")) {
         int v = atoi(env);
         if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->msm_pieces = v;
