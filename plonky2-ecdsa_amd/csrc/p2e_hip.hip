@@ -525,6 +525,10 @@ struct p2e_ctx {
     static constexpr int MAX_SEG = 2 * MAX_PIECES + 2;
     // st_binv, st_c2: second phase-B and second phase-C stream of the small-batch plan
     hipStream_t st_msm = nullptr, st_fixed = nullptr, st_binv = nullptr, st_c2 = nullptr;
+    // st_c1: the library's OWN first expansion stream (stream_layout with a '1'): the caller's stream then only starts the
+    // call (scalar phase) and ends it (finalisation); st_pad: spare streams that only exist to occupy hardware queues
+    hipStream_t st_c1 = nullptr, st_pad[8] = {};
+    hipEvent_t ev_c1join = nullptr;
     hipEvent_t ev_c2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_fixed = nullptr, ev_piece[MAX_SEG] = {}, ev_binv[MAX_SEG] = {};
     // one event pair around every expansion launch; kind 0 = k_expand (op by op), 1 = k_expand_runs, 2 = k_expand_fb_run
@@ -817,10 +821,51 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     int prio_lo = 0, prio_hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIP_TRY(hipStreamCreateWithPriority(&c->st_msm, hipStreamNonBlocking, prio_hi));
-    HIP_TRY(hipStreamCreateWithPriority(&c->st_fixed, hipStreamNonBlocking, prio_hi));
-    HIP_TRY(hipStreamCreateWithPriority(&c->st_binv, hipStreamNonBlocking, prio_hi));
-    HIP_TRY(hipStreamCreateWithPriority(&c->st_c2, hipStreamNonBlocking, prio_lo));
+    // Internal streams, created AND bound to their hardware queues (one empty launch each) in the order of the layout
+    // string: M / F / B = the two chain streams and the second inversion stream (high priority), 2 = the second expansion
+    // stream of the small-batch plan (low priority), 1 = an own first expansion stream (normal priority; without it the
+    // caller's stream carries the expansions), P = a spare stream.  HIP binds a hardware queue to a stream at its first
+    // launch and hands queues out in that order; queues that end up as neighbours on a hardware pipe delay each other's
+    // dispatch while one of them sits at a dependency barrier (profiles/r03_stream_order_*: the +-20 % "creation order"
+    // effect of round 2 is the caller's queue landing on the pipe of st_c2 or st_binv).  With every stream the pipeline
+    // dispatches on created here, back to back, their relative placement no longer depends on what the caller did first.
+    {
+        const char* layout = getenv("P2E_STREAM_LAYOUT");
+        if (!layout || !*layout) layout = "MFB2";
+        const char* tenv = getenv("P2E_TOUCH_STREAMS");
+        const bool touch = !tenv || atoi(tenv) != 0;
+        if (touch) {   // the legacy default stream first: a caller that has not touched the GPU yet gets its queue now
+            hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, (hipStream_t)0);
+            HIP_TRY(hipStreamSynchronize((hipStream_t)0));
+            hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, c->stream);
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        int pads = 0;
+        for (const char* p = layout; *p; p++) {
+            hipStream_t* slot = nullptr;
+            int prio = prio_hi;
+            switch (*p) {
+            case 'M': slot = &c->st_msm; break;
+            case 'F': slot = &c->st_fixed; break;
+            case 'B': slot = &c->st_binv; break;
+            case '2': slot = &c->st_c2; prio = prio_lo; break;
+            case '1': slot = &c->st_c1; prio = 0; break;
+            case 'P': if (pads < 8) slot = &c->st_pad[pads++]; prio = 0; break;
+            default: break;
+            }
+            if (!slot || *slot) continue;
+            HIP_TRY(hipStreamCreateWithPriority(slot, hipStreamNonBlocking, prio));
+            if (touch) {
+                hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, *slot);
+                HIP_TRY(hipStreamSynchronize(*slot));
+            }
+        }
+        if (!c->st_msm) HIP_TRY(hipStreamCreateWithPriority(&c->st_msm, hipStreamNonBlocking, prio_hi));
+        if (!c->st_fixed) HIP_TRY(hipStreamCreateWithPriority(&c->st_fixed, hipStreamNonBlocking, prio_hi));
+        if (!c->st_binv) HIP_TRY(hipStreamCreateWithPriority(&c->st_binv, hipStreamNonBlocking, prio_hi));
+        if (!c->st_c2) HIP_TRY(hipStreamCreateWithPriority(&c->st_c2, hipStreamNonBlocking, prio_lo));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_c1join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_c2, hipEventDisableTiming));
     for (auto& e : c->ev_binv) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -828,23 +873,6 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     for (auto& e : c->ev_piece) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_c0) HIP_TRY(hipEventCreate(&e));
     for (auto& e : c->ev_c1) HIP_TRY(hipEventCreate(&e));
-    // HIP binds a hardware queue to a stream at the stream's FIRST launch, not at its creation, and hands the queues out
-    // in that order; which queues end up as neighbours on a hardware pipe depends on it.  Measured in round 2: the step
-    // time of the small and mid-size plans moved by +-10...20 % with whether the caller's first GPU work came before or
-    // after this context's.  So the order is fixed HERE, once, the same for every caller: the
-    // legacy default stream first (a caller that has not touched the GPU yet gets its queue now instead of in the middle
-    // of ours), then the context's streams in the order below.  P2E_TOUCH_STREAMS=0 restores the lazy binding.
-    {
-        const char* env = getenv("P2E_TOUCH_STREAMS");
-        if (!env || atoi(env) != 0) {
-            hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, (hipStream_t)0);
-            HIP_TRY(hipStreamSynchronize((hipStream_t)0));
-            for (hipStream_t st : {c->stream, c->st_msm, c->st_fixed, c->st_binv, c->st_c2}) {
-                hipLaunchKernelGGL(k_touch, dim3(1), dim3(64), 0, st);
-                HIP_TRY(hipStreamSynchronize(st));
-            }
-        }
-    }
     if (const char* env = getenv("P2E_MSM_PIECES")) {
         int v = atoi(env);
         if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->msm_pieces = v;
@@ -891,12 +919,13 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_binv)
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t st : {c->st_msm, c->st_fixed, c->st_binv, c->st_c2})
+    for (hipStream_t st : {c->st_msm, c->st_fixed, c->st_binv, c->st_c2, c->st_c1, c->st_pad[0], c->st_pad[1], c->st_pad[2], c->st_pad[3],
+                           c->st_pad[4], c->st_pad[5], c->st_pad[6], c->st_pad[7]})
         if (st) {
             (void)hipStreamSynchronize(st);
             (void)hipStreamDestroy(st);
         }
-    for (hipEvent_t e : {c->ev_fork, c->ev_fixed, c->ev_c2})
+    for (hipEvent_t e : {c->ev_fork, c->ev_fixed, c->ev_c2, c->ev_c1join})
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_piece)
         if (e) (void)hipEventDestroy(e);
@@ -1114,7 +1143,7 @@ struct Staged {
     // it may still be running when the staged buffers are freed or the scratch is reused by the next call.
     void release(bool failed) {
         if (failed) {
-            for (hipStream_t st : {c->st_msm, c->st_fixed, c->st_binv, c->st_c2})
+            for (hipStream_t st : {c->st_msm, c->st_fixed, c->st_binv, c->st_c2, c->st_c1})
                 if (st) (void)hipStreamSynchronize(st);
             (void)hipStreamSynchronize(c->stream);
             (void)hipGetLastError();
@@ -1531,6 +1560,9 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     HIP_TRY(hipStreamWaitEvent(c->st_msm, c->ev_fork, 0));
     HIP_TRY(hipStreamWaitEvent(c->st_fixed, c->ev_fork, 0));
     if (alt_b) HIP_TRY(hipStreamWaitEvent(c->st_binv, c->ev_fork, 0));
+    // first expansion stream: the library's own if the layout has one (the caller's stream then waits for it at the end)
+    hipStream_t st_c1 = c->st_c1 ? c->st_c1 : c->stream;
+    if (c->st_c1) HIP_TRY(hipStreamWaitEvent(c->st_c1, c->ev_fork, 0));
     // chains
     for (int k = 0; k < ns; k++) {
         Seg& sg = segs[k];
@@ -1603,7 +1635,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         }
         // (small-batch plan: phase C alternates between the caller's stream and a second one, so that an expansion
         // waiting for its inversion batch does not hold up the expansions queued behind it)
-        hipStream_t st_c = (quad && (q & 1)) ? c->st_c2 : c->stream;
+        hipStream_t st_c = (quad && (q & 1)) ? c->st_c2 : st_c1;
         used_c2 = used_c2 || st_c == c->st_c2;
         HIP_TRY(hipStreamWaitEvent(st_c, c->ev_binv[k], 0));
         // an expansion also reads affine results of EARLIER pieces (the first operand of its first op, the window
@@ -1653,6 +1685,10 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     if (used_c2) {   // join the second expansion stream
         HIP_TRY(hipEventRecord(c->ev_c2, c->st_c2));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_c2, 0));
+    }
+    if (c->st_c1) {
+        HIP_TRY(hipEventRecord(c->ev_c1join, c->st_c1));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_c1join, 0));
     }
     HIP_TRY(hipEventRecord(c->ev[5], c->stream));
     hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, B.err, B.valid, err, valid, n, c->d_counter);
