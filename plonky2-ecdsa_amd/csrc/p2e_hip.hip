@@ -831,7 +831,12 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     // dispatches on created here, back to back, their relative placement no longer depends on what the caller did first.
     {
         const char* layout = getenv("P2E_STREAM_LAYOUT");
-        if (!layout || !*layout) layout = "MFB2";
+        // default: chain stream, OWN expansion stream, second chain stream, second inversion stream, second expansion
+        // stream.  Of twelve layouts swept on two boxes (profiles/r03_stream_layout_sweep_box*.txt, one process per
+        // setting) this is one of two whose step time is the same within 3 % whether the caller touched the GPU before
+        // or after creating the context, at 2^13 ... 2^16 per call: 2.45 / 4.0-4.1 / 6.0-6.1 / 10.8 ms, against 2.29 or
+        // 2.77 / 4.15 or 3.95 / 6.0 / 10.8 ms for the round-2 placement "MFB2" with the expansions on the caller's stream.
+        if (!layout || !*layout) layout = "M1FB2";
         const char* tenv = getenv("P2E_TOUCH_STREAMS");
         const bool touch = !tenv || atoi(tenv) != 0;
         if (touch) {   // the legacy default stream first: a caller that has not touched the GPU yet gets its queue now
