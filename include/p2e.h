@@ -95,7 +95,7 @@ int p2e_last_phase_ms(p2e_ctx *ctx, float *out, int cap);
 /* The reference fills a PartialWitness generator by generator; a batch consumer -- the RCCL exchange that assembles the
  * columns of a sharded batch on every rank, a D2H copy, a prover that starts on finished columns -- need not wait for
  * the whole call either.  Every fused entry point (p2e_ecdsa_verify_witness[_compact]_batch, p2e_glv_mul_witness
- * [_compact]_batch, p2e_curve_mul_witness_batch, p2e_p256_verify_witness_batch) leaves behind, per launch that writes
+ * [_compact]_batch, p2e_curve_mul_witness[_compact]_batch, p2e_p256_verify_witness[_compact]_batch) leaves behind, per launch that writes
  * witness columns, the block of columns [first_col, first_col + num_cols) it completes and a HIP event recorded behind
  * it.  Blocks are disjoint, cover all columns of the program, and are listed in the order the launches were issued
  * (the scalar phase first, then the expansion of every schedule piece as its chain and inversion batch finish).  In
@@ -396,6 +396,20 @@ long p2e_curve_mul_witness_batch(p2e_ctx *ctx, const p2e_curve_program *prog, co
 long p2e_p256_verify_witness_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *msg32, const uint8_t *r32,
                                    const uint8_t *s32, const uint8_t *pkx32, const uint8_t *pky32, uint64_t *cols, size_t n,
                                    size_t ld, uint8_t *err, uint8_t *valid);
+/* Both fills writing the COMPACT container instead (as p2e_ecdsa_verify_witness_compact_batch: u32 narrow[num_narrow]
+ * [ld_narrow] for the columns that only ever hold values < 2^32 -- 29-bit limbs, overflow words, flags --, u64
+ * wide[num_wide][ld_wide] for the check_sum / carry columns of the mul generators; both indices advance in generator
+ * registration order).  p2e_curve_program_compact_layout: col_map[c] = narrow row of witness column c, or
+ * P2E_COMPACT_WIDE | wide row; returns num_cols. */
+long p2e_curve_mul_witness_compact_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *px32, const uint8_t *py32,
+                                         const uint8_t *k32, uint32_t *narrow, size_t ld_narrow, uint64_t *wide, size_t ld_wide,
+                                         size_t n, uint8_t *err, uint8_t *valid);
+long p2e_p256_verify_witness_compact_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *msg32, const uint8_t *r32,
+                                           const uint8_t *s32, const uint8_t *pkx32, const uint8_t *pky32, uint32_t *narrow,
+                                           size_t ld_narrow, uint64_t *wide, size_t ld_wide, size_t n, uint8_t *err,
+                                           uint8_t *valid);
+long p2e_curve_program_compact_layout(const p2e_curve_program *prog, uint32_t *col_map, size_t cap, uint32_t *num_narrow,
+                                      uint32_t *num_wide);
 /* the P-256 verifier's verdict alone (the counterpart of p2e_ecdsa_verify_batch; native: curve/ecdsa.rs:42-62
  * verify_message with C = P256, with exactly the circuit's verdict): no witness, 2 bytes per signature */
 long p2e_p256_verify_batch(p2e_ctx *ctx, const p2e_curve_program *prog, const uint8_t *msg32, const uint8_t *r32,

@@ -69,6 +69,7 @@ EXPORTS = (
     "p2e_curve_program_num_gate_cols", "p2e_curve_program_num_ux_cols", "p2e_curve_program_ux_describe",
     "p2e_curve_program_aux_witness_batch", "p2e_curve_program_gate_internal_batch", "p2e_curve_program_ux_witness_batch",
     "p2e_curve_program_wire_map_create", "p2e_p256_verify_batch",
+    "p2e_curve_mul_witness_compact_batch", "p2e_p256_verify_witness_compact_batch", "p2e_curve_program_compact_layout",
 )
 
 
@@ -143,7 +144,7 @@ def lib():
                                                    "p2e_curve_program_num_aux_cols", "p2e_curve_program_describe",
                                                    "p2e_curve_program_wiring", "p2e_curve_program_aux_describe",
                                                    "p2e_curve_program_num_gate_cols", "p2e_curve_program_num_ux_cols",
-                                                   "p2e_curve_program_ux_describe"):
+                                                   "p2e_curve_program_ux_describe", "p2e_curve_program_compact_layout"):
                 getattr(_lib, name).restype = C.c_long
         _lib.p2e_curve_program_scratch_bytes.restype = C.c_size_t
     return _lib
@@ -378,6 +379,63 @@ class CurveProgram:
         bad = ctx._check(ctx._L.p2e_curve_mul_witness_batch(ctx._h, self._h, _ptr(px), _ptr(py), _ptr(k), _ptr(cols), C.c_size_t(n),
                                                             C.c_size_t(ld), _ptr(err), _ptr(valid)))
         return cols, err, valid, bad
+
+    # ---- the compact container (include/p2e.h p2e_curve_program_compact_layout) -----------------------------------
+    def compact_layout(self):
+        """(col_map, num_narrow, num_wide): col_map[c] = row of witness column c in the u32 narrow matrix, or
+        COMPACT_WIDE | row in the u64 wide one."""
+        L = self._ctx._L
+        m = np.zeros(self.num_cols, dtype=np.uint32)
+        nn, nw = C.c_uint32(), C.c_uint32()
+        L.p2e_curve_program_compact_layout(self._h, _ptr(m), C.c_size_t(self.num_cols), C.byref(nn), C.byref(nw))
+        return m, int(nn.value), int(nw.value)
+
+    def compact_expand(self, narrow, wide):
+        """host-side inverse (numpy): the (num_cols, n) u64 matrix of a compact container of this program"""
+        m, _nn, _nw = self.compact_layout()
+        out = np.empty((len(m), narrow.shape[1]), dtype=np.uint64)
+        is_wide = (m & COMPACT_WIDE) != 0
+        out[~is_wide] = np.asarray(narrow).view(np.uint32)[m[~is_wide]]
+        out[is_wide] = np.asarray(wide).view(np.uint64)[m[is_wide] & 0x7FFFFFFF]
+        return out
+
+    def _compact_out(self, n, narrow, wide, err, valid, ld_narrow, ld_wide):
+        ctx = self._ctx
+        _m, nn, nw = self.compact_layout()
+        if narrow is None or wide is None:
+            ldp = n + 16 if (not ctx.host_pointers and n >= 4096 and n & (n - 1) == 0) else n
+            if ctx.host_pointers:
+                narrow, wide = np.zeros((nn, ldp), dtype=np.uint32), np.zeros((nw, ldp), dtype=np.uint64)
+            else:
+                import torch
+                dev = f"cuda:{ctx.device}"
+                narrow = torch.empty((nn, ldp), dtype=torch.int32, device=dev)
+                wide = torch.empty((nw, ldp), dtype=torch.int64, device=dev)
+            narrow, wide = narrow[:, :n], wide[:, :n]
+        err = err if err is not None else ctx._vec(n, np.uint8)
+        valid = valid if valid is not None else ctx._vec(n, np.uint8)
+        return narrow, wide, err, valid, ld_narrow or _ld(narrow), ld_wide or _ld(wide)
+
+    def mul_witness_compact_batch(self, px, py, k, narrow=None, wide=None, err=None, valid=None, ld_narrow=None, ld_wide=None):
+        """mul_witness_batch writing the compact container: (narrow u32, wide u64, err, valid, bad)"""
+        ctx = self._ctx
+        n = ctx._shape(px)[0]
+        narrow, wide, err, valid, ldn, ldw = self._compact_out(n, narrow, wide, err, valid, ld_narrow, ld_wide)
+        ctx._L.p2e_curve_mul_witness_compact_batch.restype = C.c_long
+        bad = ctx._check(ctx._L.p2e_curve_mul_witness_compact_batch(ctx._h, self._h, _ptr(px), _ptr(py), _ptr(k), _ptr(narrow), C.c_size_t(ldn),
+                                                                    _ptr(wide), C.c_size_t(ldw), C.c_size_t(n), _ptr(err), _ptr(valid)))
+        return narrow, wide, err, valid, bad
+
+    def verify_witness_compact_batch(self, msg, r, s, pkx, pky, narrow=None, wide=None, err=None, valid=None, ld_narrow=None, ld_wide=None):
+        """verify_witness_batch writing the compact container: (narrow u32, wide u64, err, valid, bad)"""
+        ctx = self._ctx
+        n = ctx._shape(msg)[0]
+        narrow, wide, err, valid, ldn, ldw = self._compact_out(n, narrow, wide, err, valid, ld_narrow, ld_wide)
+        ctx._L.p2e_p256_verify_witness_compact_batch.restype = C.c_long
+        bad = ctx._check(ctx._L.p2e_p256_verify_witness_compact_batch(ctx._h, self._h, _ptr(msg), _ptr(r), _ptr(s), _ptr(pkx), _ptr(pky),
+                                                                      _ptr(narrow), C.c_size_t(ldn), _ptr(wide), C.c_size_t(ldw), C.c_size_t(n),
+                                                                      _ptr(err), _ptr(valid)))
+        return narrow, wide, err, valid, bad
 
     def _inputs(self, inputs):
         """(msg, r, s, pkx, pky) pointers from the program's input tuple: (px, py, k) or (msg, r, s, pkx, pky)"""

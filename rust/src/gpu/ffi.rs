@@ -209,4 +209,13 @@ extern "C" {
     pub fn p2e_p256_verify_witness_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, msg32: *const u8, r32: *const u8,
         s32: *const u8, pkx32: *const u8, pky32: *const u8, cols: *mut u64, n: usize, ld: usize, err: *mut u8,
         valid: *mut u8) -> i64;
+    // the same two fills into the compact container (u32 narrow + u64 wide matrices), and its column map
+    pub fn p2e_curve_mul_witness_compact_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, px32: *const u8, py32: *const u8,
+        k32: *const u8, narrow: *mut u32, ld_narrow: usize, wide: *mut u64, ld_wide: usize, n: usize, err: *mut u8,
+        valid: *mut u8) -> i64;
+    pub fn p2e_p256_verify_witness_compact_batch(ctx: *mut P2eCtx, prog: *const P2eCurveProgram, msg32: *const u8, r32: *const u8,
+        s32: *const u8, pkx32: *const u8, pky32: *const u8, narrow: *mut u32, ld_narrow: usize, wide: *mut u64, ld_wide: usize,
+        n: usize, err: *mut u8, valid: *mut u8) -> i64;
+    pub fn p2e_curve_program_compact_layout(prog: *const P2eCurveProgram, col_map: *mut u32, cap: usize, num_narrow: *mut u32,
+        num_wide: *mut u32) -> i64;
 }

@@ -599,6 +599,49 @@ def test_gpu_run_plan_of_the_curve_programs_on_a_ragged_batch(name, monkeypatch)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("plan", ["op_by_op", "runs"])
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_gpu_compact_container_of_the_curve_programs(name, plan, monkeypatch):
+    """The curve programs writing the compact container directly (u32 narrow + u64 wide matrices, padded strides, a ragged
+    batch: paired 8- / 16-byte stores + the tail kernels), both launch plans: expanded on the host it must be the C
+    oracle's matrix on every column of every input; the pad columns stay untouched."""
+    import oracle_c
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    m = META[name]
+    if plan == "runs":
+        if m["kind"] == 2:
+            pytest.skip("curve_scalar_mul has no window loop: one plan only")
+        monkeypatch.setenv("P2E_CP_RUNS_MIN_N", "1")
+    ctx = p2e.Context(device=0)
+    cv = CURVES[m["curve"]]
+    blind_i, blind = _blind_of(cv, R.SplitMix64(777 + m["kind"] + 10 * m["curve"]))
+    n = 600 + 37
+    args = _ragged_inputs(p2e, m, n, 99 + m["kind"])
+    prog = p2e.CurveProgram(ctx, m["kind"], m["curve"], blind_i)
+    cmap, nn, nw = prog.compact_layout()
+    assert nn + nw == m["num_cols"] and len(cmap) == m["num_cols"]
+    nar = torch.full((nn, n + 3), -1, dtype=torch.int32, device="cuda")
+    wid = torch.full((nw, n + 5), -1, dtype=torch.int64, device="cuda")
+    dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in args]
+    if m["kind"] == 3:
+        _, _, err, valid, bad = prog.verify_witness_compact_batch(*dev, narrow=nar[:, :n], wide=wid[:, :n], ld_narrow=n + 3, ld_wide=n + 5)
+    else:
+        _, _, err, valid, bad = prog.mul_witness_compact_batch(*dev, narrow=nar[:, :n], wide=wid[:, :n], ld_narrow=n + 3, ld_wide=n + 5)
+    torch.cuda.synchronize()
+    ocols, _a, oerr, oflags = oracle_c.curve_program(m["kind"], m["curve"], blind, args, want_aux=False)
+    got = prog.compact_expand(nar[:, :n].cpu().numpy(), wid[:, :n].cpu().numpy())
+    assert bad == 0 and np.array_equal(err.cpu().numpy(), oerr) and np.array_equal(valid.cpu().numpy(), oflags)
+    assert np.array_equal(got, ocols)
+    assert bool((nar[:, n:] == -1).all()) and bool((wid[:, n:] == -1).all())
+    # even strides: the paired-store kernels; same container
+    nar2, wid2, _, _, bad2 = (prog.verify_witness_compact_batch(*dev) if m["kind"] == 3 else prog.mul_witness_compact_batch(*dev))
+    torch.cuda.synchronize()
+    assert bad2 == 0 and torch.equal(nar2, nar[:, :n]) and torch.equal(wid2, wid[:, :n])
+    prog.close()
+
+
+@pytest.mark.gpu
 def test_gpu_p256_verifier_full_size_batch_every_signature():
     """verify_p256_message_circuit at 2^16 per call -- the plan bench.py's p256_verify leg reports (runs, fixed-base run,
     its own chain stream) -- compared with the C oracle's lock-step walk on EVERY signature and column: 2 048 distinct
