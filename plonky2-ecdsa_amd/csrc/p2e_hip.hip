@@ -528,6 +528,9 @@ struct p2e_ctx {
     // st_c1: the library's OWN first expansion stream (stream_layout with a '1'): the caller's stream then only starts the
     // call (scalar phase) and ends it (finalisation); st_pad: spare streams that only exist to occupy hardware queues
     hipStream_t st_c1 = nullptr, st_pad[8] = {};
+    // experiment (P2E_QUAD_EXPAND_CUS=k): expansion streams of the four-lane plan restricted to k compute units, so that
+    // the latency-critical chain waves find SIMDs the HBM-bound expansions do not occupy
+    hipStream_t st_c1q = nullptr, st_c2q = nullptr;
     hipEvent_t ev_c1join = nullptr;
     hipEvent_t ev_c2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_fixed = nullptr, ev_piece[MAX_SEG] = {}, ev_binv[MAX_SEG] = {};
@@ -871,6 +874,21 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         if (!c->st_c2) HIP_TRY(hipStreamCreateWithPriority(&c->st_c2, hipStreamNonBlocking, prio_lo));
     }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_c1join, hipEventDisableTiming));
+    if (const char* env = getenv("P2E_QUAD_EXPAND_CUS")) {
+        const int k = atoi(env);
+        int ncu = 0;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        if (k > 0 && k < ncu) {
+            const char* pat = getenv("P2E_QUAD_EXPAND_CU_PATTERN");   // "low" (default): CUs 0..k-1; "stride": every (ncu/k)-th
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int i = 0; i < k; i++) {
+                const int cu = (pat && pat[0] == 's') ? (int)((long long)i * ncu / k) : i;
+                mask[(size_t)cu >> 5] |= 1u << (cu & 31);
+            }
+            HIP_TRY(hipExtStreamCreateWithCUMask(&c->st_c1q, (uint32_t)mask.size(), mask.data()));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&c->st_c2q, (uint32_t)mask.size(), mask.data()));
+        }
+    }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_c2, hipEventDisableTiming));
     for (auto& e : c->ev_binv) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -924,7 +942,7 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_binv)
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t st : {c->st_msm, c->st_fixed, c->st_binv, c->st_c2, c->st_c1, c->st_pad[0], c->st_pad[1], c->st_pad[2], c->st_pad[3],
+    for (hipStream_t st : {c->st_msm, c->st_fixed, c->st_binv, c->st_c2, c->st_c1, c->st_c1q, c->st_c2q, c->st_pad[0], c->st_pad[1], c->st_pad[2], c->st_pad[3],
                            c->st_pad[4], c->st_pad[5], c->st_pad[6], c->st_pad[7]})
         if (st) {
             (void)hipStreamSynchronize(st);
@@ -1148,7 +1166,7 @@ struct Staged {
     // it may still be running when the staged buffers are freed or the scratch is reused by the next call.
     void release(bool failed) {
         if (failed) {
-            for (hipStream_t st : {c->st_msm, c->st_fixed, c->st_binv, c->st_c2, c->st_c1})
+            for (hipStream_t st : {c->st_msm, c->st_fixed, c->st_binv, c->st_c2, c->st_c1, c->st_c1q, c->st_c2q})
                 if (st) (void)hipStreamSynchronize(st);
             (void)hipStreamSynchronize(c->stream);
             (void)hipGetLastError();
@@ -1567,7 +1585,13 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     if (alt_b) HIP_TRY(hipStreamWaitEvent(c->st_binv, c->ev_fork, 0));
     // first expansion stream: the library's own if the layout has one (the caller's stream then waits for it at the end)
     hipStream_t st_c1 = c->st_c1 ? c->st_c1 : c->stream;
-    if (c->st_c1) HIP_TRY(hipStreamWaitEvent(c->st_c1, c->ev_fork, 0));
+    hipStream_t st_c2 = c->st_c2;
+    const bool own_c1 = c->st_c1 != nullptr || (quad && c->st_c1q);
+    if (quad && c->st_c1q) {
+        st_c1 = c->st_c1q;
+        st_c2 = c->st_c2q;
+    }
+    if (own_c1) HIP_TRY(hipStreamWaitEvent(st_c1, c->ev_fork, 0));
     // chains
     for (int k = 0; k < ns; k++) {
         Seg& sg = segs[k];
@@ -1640,8 +1664,8 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         }
         // (small-batch plan: phase C alternates between the caller's stream and a second one, so that an expansion
         // waiting for its inversion batch does not hold up the expansions queued behind it)
-        hipStream_t st_c = (quad && (q & 1)) ? c->st_c2 : st_c1;
-        used_c2 = used_c2 || st_c == c->st_c2;
+        hipStream_t st_c = (quad && (q & 1)) ? st_c2 : st_c1;
+        used_c2 = used_c2 || st_c == st_c2;
         HIP_TRY(hipStreamWaitEvent(st_c, c->ev_binv[k], 0));
         // an expansion also reads affine results of EARLIER pieces (the first operand of its first op, the window
         // table, the fixed-base result under the final add): with one expansion stream the queue order implied
@@ -1688,11 +1712,11 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         }
     }
     if (used_c2) {   // join the second expansion stream
-        HIP_TRY(hipEventRecord(c->ev_c2, c->st_c2));
+        HIP_TRY(hipEventRecord(c->ev_c2, st_c2));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_c2, 0));
     }
-    if (c->st_c1) {
-        HIP_TRY(hipEventRecord(c->ev_c1join, c->st_c1));
+    if (own_c1) {
+        HIP_TRY(hipEventRecord(c->ev_c1join, st_c1));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_c1join, 0));
     }
     HIP_TRY(hipEventRecord(c->ev[5], c->stream));
