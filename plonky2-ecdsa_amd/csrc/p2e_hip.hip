@@ -488,6 +488,7 @@ struct DeviceProgram {
     OpDesc* d_ops = nullptr;        // with the run marks of ctx->run_iters (F_NO_AFFINE)
     OpDesc* d_ops_plain = nullptr;  // without: every op expanded on its own (small batches)
     OpDesc* d_ops_mid = nullptr;    // with the run marks of ctx->run_iters_mid (mid-size batches)
+    OpDesc* d_ops_small = nullptr;  // with the run marks of ctx->run_iters_small (four-lane plan)
     std::vector<OpDesc> h_ops;
     std::vector<host::GenOp> gens;
     // built-in-generator columns (aux.hpp)
@@ -573,6 +574,11 @@ struct p2e_ctx {
     // ... and the loop is cut into fewer pieces of longer runs there (5 pieces of 12-iteration runs instead of 8 of 9:
     // 5.96 against 6.45 ms at 2^15, 7.65 against 7.95 ms at 40 960, 9.15 against 9.53 ms at 48 896)
     int msm_pieces_mid = 5, run_iters_mid = 12;
+    // four-lane plan: the loop expanded as SHORT runs (4 iterations = 12 ops, two of them keep their affine form): phase B
+    // then does 3 instead of 8 multiplications for the other ten, and a piece of 5 runs still launches 5 * n/64 waves.
+    // 2.35 / 2.27 against 2.42 ms at 2^13, 2.88 / 2.96 against 3.05 ms at 12 288 (profiles/r03_quad_plan_run_expansion_sweep.txt;
+    // R = 2, 3, 6 and 7 pieces are slower).  0: every op expanded on its own, as in round 2.
+    int run_iters_small = 4;
     int binv_mid_split_log2 = 1;   // 2^15 per call: 7.03-7.08 ms on one stream, 6.76-6.83 alternating, 6.68-6.72 alternating and split in two
     int binv_split_log2 = 2;
     // small-batch plan: dynamic LDS bytes requested by the expansion kernels (they do not use it): caps how many of
@@ -751,6 +757,10 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         int v = atoi(env);
         if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->msm_pieces_mid = v;
     }
+    if (const char* env = getenv("P2E_RUN_ITERS_SMALL")) {
+        int v = atoi(env);
+        if (v >= 0 && v <= MSM_DIGITS) c->run_iters_small = v;
+    }
     if (const char* env = getenv("P2E_RUN_ITERS_MID")) {
         int v = atoi(env);
         if (v >= 0 && v <= MSM_DIGITS) c->run_iters_mid = v;
@@ -815,6 +825,9 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         std::vector<OpDesc> mid = host_ops(p, c->run_iters_mid, c->fb_run);
         HIP_TRY(hipMalloc(&c->progs[p].d_ops_mid, sizeof(OpDesc) * mid.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_ops_mid, mid.data(), sizeof(OpDesc) * mid.size(), hipMemcpyHostToDevice));
+        std::vector<OpDesc> small = host_ops(p, c->run_iters_small, c->fb_run);
+        HIP_TRY(hipMalloc(&c->progs[p].d_ops_small, sizeof(OpDesc) * small.size()));
+        HIP_TRY(hipMemcpy(c->progs[p].d_ops_small, small.data(), sizeof(OpDesc) * small.size(), hipMemcpyHostToDevice));
         std::vector<OpDesc> plain = host_ops(p, 0);
         HIP_TRY(hipMalloc(&c->progs[p].d_ops_plain, sizeof(OpDesc) * plain.size()));
         HIP_TRY(hipMemcpy(c->progs[p].d_ops_plain, plain.data(), sizeof(OpDesc) * plain.size(), hipMemcpyHostToDevice));
@@ -930,6 +943,7 @@ extern "C" void p2e_ctx_destroy(p2e_ctx* c) {
         (void)hipFree(p.d_ops);
         (void)hipFree(p.d_ops_plain);
         (void)hipFree(p.d_ops_mid);
+        (void)hipFree(p.d_ops_small);
         (void)hipFree(p.d_aux_items);
         (void)hipFree(p.d_aux_tab);
         (void)hipFree(p.d_compact_map);
@@ -1440,8 +1454,16 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     // three regimes: four lanes per signature (n <= quad_max_n), lane per signature with phase B on two streams and longer
     // runs in fewer pieces (below binv_alt_max_n), and the large-batch plan
     const bool mid_plan = n > c->quad_max_n && n < c->binv_alt_max_n;
-    const int run_iters = n >= c->runs_min_n ? (mid_plan ? c->run_iters_mid : c->run_iters) : 0;
-    B.ops = run_iters > 0 ? (mid_plan ? DP.d_ops_mid : DP.d_ops) : DP.d_ops_plain;
+    const bool quad_plan = n <= c->quad_max_n;
+    int run_iters = 0;
+    B.ops = DP.d_ops_plain;
+    if (n >= c->runs_min_n) {
+        run_iters = mid_plan ? c->run_iters_mid : c->run_iters;
+        if (run_iters > 0) B.ops = mid_plan ? DP.d_ops_mid : DP.d_ops;
+    } else if (quad_plan && c->run_iters_small > 0) {
+        run_iters = c->run_iters_small;
+        B.ops = DP.d_ops_small;
+    }
     ZERO_COUNTER(c);
     unsigned gx = (unsigned)((n + BS - 1) / BS);
     c->n_expand = 0;

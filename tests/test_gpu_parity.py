@@ -78,7 +78,7 @@ def test_structured_operands(gpu, ora):
     pc.check_structured_mul_add_sub(gpu, ora, count=20000)
 
 
-@pytest.mark.parametrize("plan", ["quad", "lane_per_signature", "quad_split8"])
+@pytest.mark.parametrize("plan", ["quad", "lane_per_signature", "quad_split8", "quad_op_by_op"])
 def test_verify_random_batch_ragged(ora, monkeypatch, plan):
     """n = 301: not a multiple of the wavefront / workgroup size (nor of the 64 signatures a quad workgroup holds).
     Both forms of phases A / B: four lanes per signature with split inversion batches (the default below 24 576
@@ -88,6 +88,8 @@ def test_verify_random_batch_ragged(ora, monkeypatch, plan):
     monkeypatch.setenv("P2E_QUAD_MAX_N", "0" if plan == "lane_per_signature" else "1000000")
     if plan == "quad_split8":
         monkeypatch.setenv("P2E_BINV_SPLIT_LOG2", "3")
+    if plan == "quad_op_by_op":                    # round-2 form of the four-lane plan: every op expanded on its own
+        monkeypatch.setenv("P2E_RUN_ITERS_SMALL", "0")
     gpu = GpuBackend()
     arrs = p2e.synth_signatures(seed=77, n=301)
     want, werr, wflags = ora.verify(*arrs)
@@ -184,6 +186,8 @@ def test_edge_inputs_and_error_flags(gpu, ora, monkeypatch, runs):
             ctx = p2e.Context(device=0, host_pointers=True)
             verify = lambda self, *a: self.ctx.ecdsa_verify_witness_batch(*[np.ascontiguousarray(x, np.uint8) for x in a])[:3]
         gpu = _G()
+    else:
+        monkeypatch.setenv("P2E_RUN_ITERS_SMALL", "0")
     sig = list(R.synth_signature_at(5, 0))
     rx, ry = R.rando_point()
     cases = [tuple(sig)]
@@ -285,8 +289,7 @@ def test_fused_compact_output_matches_oracle(ora, monkeypatch, runs):
     strides; both expansion kernels; both programs."""
     import torch
     import plonky2_ecdsa_amd as p2e
-    if runs:
-        monkeypatch.setenv("P2E_RUNS_MIN_N", "0")
+    monkeypatch.setenv("P2E_RUNS_MIN_N" if runs else "P2E_RUN_ITERS_SMALL", "0")
     n = 700
     sigs = p2e.synth_signatures(seed=71, n=n)
     ctx = p2e.Context(device=0)
