@@ -34,7 +34,7 @@ __device__ __forceinline__ U256 quad_bcast(const U256& v) {
 // One level: products (a0*b0, a1*b1, a2*b2, a3*b3), the first USED of them wanted.  Device: this lane multiplies the
 // pair of its role, then the quad exchanges; host (emulation): all of them, the role is irrelevant.  SQR: every
 // pair is a square (b ignored).
-template <int USED, bool SQR>
+template <int USED, bool SQR, class CV = Secp256k1>
 P2E_HD void quad_level(int role, const U256& a0, const U256& b0, const U256& a1, const U256& b1, const U256& a2,
                        const U256& b2, const U256& a3, const U256& b3, U256& r0, U256& r1, U256& r2, U256& r3) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -51,17 +51,18 @@ P2E_HD void quad_level(int role, const U256& a0, const U256& b0, const U256& a1,
         A = u256_select(role == 3, a3, A);
         if (!SQR) B = u256_select(role == 3, b3, B);
     }
-    const U256 r = SQR ? fp_sqr(A) : fp_mul(A, B);
+    const U256 r = SQR ? fe_sqr<typename CV::Fp>(A) : fe_mul<typename CV::Fp>(A, B);
     r0 = quad_bcast<0>(r);
     if (USED > 1) r1 = quad_bcast<1>(r);
     if (USED > 2) r2 = quad_bcast<2>(r);
     if (USED > 3) r3 = quad_bcast<3>(r);
 #else
     (void)role;
-    r0 = SQR ? fp_sqr(a0) : fp_mul(a0, b0);
-    if (USED > 1) r1 = SQR ? fp_sqr(a1) : fp_mul(a1, b1);
-    if (USED > 2) r2 = SQR ? fp_sqr(a2) : fp_mul(a2, b2);
-    if (USED > 3) r3 = SQR ? fp_sqr(a3) : fp_mul(a3, b3);
+    typedef typename CV::Fp F_;
+    r0 = SQR ? fe_sqr<F_>(a0) : fe_mul<F_>(a0, b0);
+    if (USED > 1) r1 = SQR ? fe_sqr<F_>(a1) : fe_mul<F_>(a1, b1);
+    if (USED > 2) r2 = SQR ? fe_sqr<F_>(a2) : fe_mul<F_>(a2, b2);
+    if (USED > 3) r3 = SQR ? fe_sqr<F_>(a3) : fe_mul<F_>(a3, b3);
 #endif
 }
 
@@ -146,6 +147,87 @@ P2E_HD QuadRes jac_add_quad(int role, const Jac& p1, bool have_zz1, const U256& 
     U256 t1, t2;
     quad_level<4, false>(role, r, fp_sub(v, o.res.p.X), s1, h3, acc, zfix, z3, z3, t1, t2, o.acc, o.zz3);
     o.res.p.Y = fp_sub(t1, t2);
+    o.res.p.Z = z3;
+    o.zz1 = zz1;
+    return o;
+}
+
+// ---- the same levels over either curve of the crate (curve programs, curves.hpp) ------------------------------------
+// a = 0: jac_dbl_quad above.  a = -3 (P-256): the slope numerator 3 (X^2 - Z^4) needs Z^4 = W first, so the doubling has
+// four levels (ec.hpp jac_dbl_cv, same Z3 = 2 Y Z and W = Z^4):
+//   1: X^2, Y^2, Y Z, Z^2      2: (Y^2)^2, (X + Y^2)^2, (Z^2)^2      3: e^2 [, acc * Z3, Z3^2]      4: e (d - X3)
+template <class CV>
+P2E_HD QuadRes jac_dbl_quad_cv(int role, const Jac& p, const U256& acc) {
+    typedef typename CV::Fp F;
+    if (CV::kAZero) return jac_dbl_quad(role, p, acc);
+    U256 a, b, yz, zz, c, t0, w, d0, f, y0;
+    quad_level<4, false, CV>(role, p.X, p.X, p.Y, p.Y, p.Y, p.Z, p.Z, p.Z, a, b, yz, zz);
+    const U256 z3 = fe_add<F>(yz, yz);
+    quad_level<3, true, CV>(role, b, b, fe_add<F>(p.X, b), b, zz, b, zz, b, c, t0, w, d0);
+    const U256 t = fe_sub<F>(fe_sub<F>(t0, a), c);
+    const U256 d = fe_add<F>(t, t);
+    const U256 e1 = fe_sub<F>(a, w);
+    const U256 e = fe_add<F>(fe_add<F>(e1, e1), e1);
+    QuadRes o;
+    o.z3_zero = u256_is_zero(z3);
+    const U256 zfix = u256_select(o.z3_zero, u256_small(1), z3);
+    quad_level<3, false, CV>(role, e, e, acc, zfix, z3, z3, z3, z3, f, o.acc, o.zz3, d0);
+    o.res.p.X = fe_sub<F>(f, fe_add<F>(d, d));
+    const U256 c2 = fe_add<F>(c, c), c4 = fe_add<F>(c2, c2), c8 = fe_add<F>(c4, c4);
+    quad_level<1, false, CV>(role, e, fe_sub<F>(d, o.res.p.X), e, e, e, e, e, e, y0, d0, d0, d0);
+    o.res.p.Y = fe_sub<F>(y0, c8);
+    o.res.p.Z = z3;
+    o.res.W = w;
+    o.zz1 = zz;
+    return o;
+}
+// jac_add_quad over CV::Fp (the formulas do not involve the curve's coefficients)
+template <class CV, bool Z1ONE, bool Z2ONE>
+P2E_HD QuadRes jac_add_quad_cv(int role, const Jac& p1, bool have_zz1, const U256& zz1_in, const Jac& p2, const U256& acc) {
+    typedef typename CV::Fp F;
+    if (CV::kAZero) return jac_add_quad<Z1ONE, Z2ONE>(role, p1, have_zz1, zz1_in, p2, acc);
+    U256 zz1 = zz1_in, zz2, z12, z1c, z2c, u1 = p1.X, u2 = p2.X, s1 = p1.Y, s2 = p2.Y, d0, d1;
+    if (!Z1ONE && !Z2ONE) {
+        quad_level<3, false, CV>(role, p1.Z, p1.Z, p2.Z, p2.Z, p1.Z, p2.Z, p1.Z, p1.Z, zz1, zz2, z12, d0);
+    } else if (!Z1ONE) {
+        if (!have_zz1) quad_level<1, true, CV>(role, p1.Z, p1.Z, p1.Z, p1.Z, p1.Z, p1.Z, p1.Z, p1.Z, zz1, d0, d1, d0);
+    } else if (!Z2ONE) {
+        quad_level<1, true, CV>(role, p2.Z, p2.Z, p2.Z, p2.Z, p2.Z, p2.Z, p2.Z, p2.Z, zz2, d0, d1, d0);
+    }
+    if (!Z1ONE && !Z2ONE) {
+        quad_level<4, false, CV>(role, zz1, p1.Z, zz2, p2.Z, p1.X, zz2, p2.X, zz1, z1c, z2c, u1, u2);
+    } else if (!Z1ONE) {
+        quad_level<2, false, CV>(role, zz1, p1.Z, p2.X, zz1, zz1, zz1, zz1, zz1, z1c, u2, d0, d1);
+    } else if (!Z2ONE) {
+        quad_level<2, false, CV>(role, zz2, p2.Z, p1.X, zz2, zz2, zz2, zz2, zz2, z2c, u1, d0, d1);
+    }
+    const U256 h = fe_sub<F>(u2, u1);
+    U256 h2, z3;
+    if (!Z1ONE && !Z2ONE) {
+        quad_level<4, false, CV>(role, p1.Y, z2c, p2.Y, z1c, h, h, z12, h, s1, s2, h2, z3);
+    } else if (!Z1ONE) {
+        quad_level<3, false, CV>(role, p2.Y, z1c, h, h, p1.Z, h, h, h, s2, h2, z3, d0);
+    } else if (!Z2ONE) {
+        quad_level<3, false, CV>(role, p1.Y, z2c, h, h, p2.Z, h, h, h, s1, h2, z3, d0);
+    } else {
+        quad_level<1, true, CV>(role, h, h, h, h, h, h, h, h, h2, d0, d1, d0);
+        z3 = h;
+    }
+    const U256 r = fe_sub<F>(s2, s1);
+    U256 h3, v, r2;
+    QuadRes o;
+    if (!Z1ONE && !Z2ONE) {
+        quad_level<4, false, CV>(role, h2, h, u1, h2, r, r, z1c, z2c, h3, v, r2, o.res.W);
+    } else {
+        quad_level<3, false, CV>(role, h2, h, u1, h2, r, r, r, r, h3, v, r2, d0);
+        o.res.W = Z1ONE ? (Z2ONE ? u256_small(1) : z2c) : z1c;
+    }
+    o.res.p.X = fe_sub<F>(fe_sub<F>(r2, h3), fe_add<F>(v, v));
+    o.z3_zero = u256_is_zero(z3);
+    const U256 zfix = u256_select(o.z3_zero, u256_small(1), z3);
+    U256 t1, t2;
+    quad_level<4, false, CV>(role, r, fe_sub<F>(v, o.res.p.X), s1, h3, acc, zfix, z3, z3, t1, t2, o.acc, o.zz3);
+    o.res.p.Y = fe_sub<F>(t1, t2);
     o.res.p.Z = z3;
     o.zz1 = zz1;
     return o;
@@ -486,12 +568,91 @@ P2E_HD void body_chain_range_quad(const Program& G, const Buffers& B, size_t i, 
 // Phase B of ops [t0, t1) with the backward pass cut into S sub-ranges; this lane walks sub-range q.  With phase A's
 // cumulative prefix products (have_prefix) a sub-range starts from the inverse of the product THROUGH its last op,
 // which is one inversion of its own: S inversions run side by side instead of one followed by a t1 - t0 long walk.
+template <class CV = Secp256k1>
 P2E_HD void body_batch_inv_split(const Program& G, const Buffers& B, size_t i, int t0, int t1, bool have_prefix, int q, int S) {
     const int len = t1 - t0;
     const int a = t0 + (int)(((long long)len * q) / S), b = t0 + (int)(((long long)len * (q + 1)) / S);
     if (a >= b) return;
     // (have_prefix: PREF[t] is the product from the piece's first op, so [a, b) needs no forward pass of its own)
-    body_batch_inv(G, B, i, a, b, have_prefix, false);   // lanes of one wave walk different ops
+    body_batch_inv<CV>(G, B, i, a, b, have_prefix, false);   // lanes of one wave walk different ops
+}
+
+// ---- curve programs (curves.hpp): any op list of either curve, four lanes per signature ------------------------------
+// body_chain_op<CV, true> (pipeline.hpp) for a quad: the generic walker only -- the windowed loop is not written out as
+// straight-line code the way the built-in MSM loop is, so operand loads are settled where they are issued.
+template <class CV>
+P2E_HD void body_chain_op_quad_cv(const Program& G, const Buffers& B, size_t i, int role, int t, const OpDesc& op, bool table_affine,
+                                  const P1Sel& s1, ChainStateQ& st) {
+    const uint16_t src1 = s1.src1;
+    const Jac& p1 = s1.p1;
+    if (role == 0) B.src[(size_t)(2 * t) * B.n + i] = src1;
+    QuadRes q;
+    if (op.kind == OP_DBL) {
+        q = jac_dbl_quad_cv<CV>(role, p1, st.acc);
+    } else {
+        Jac p2;
+        u32 digit = 1;
+        uint16_t src2;
+        bool z2one = (op.flags & F_Z2ONE) != 0;
+        if (ref_kind(op.ref2) == R_SELSLOT) {   // curve_scalar_mul: result + 2^i p, selected by bit i
+            digit = B.dig2[(size_t)(ref_id(op.ref2) >> 12) * B.n + i];
+            src2 = (uint16_t)(ref_id(op.ref2) & 0xFFFu);
+            p2 = load_jac_src(B, i, src2, z2one);
+        } else if (ref_kind(op.ref2) == R_FBTAB) {
+            Aff a = load_fbtab(B, i, ref_id(op.ref2), digit);
+            p2 = jac_from_aff(a);
+            src2 = (uint16_t)(SRC_FB_BIT | (ref_id(op.ref2) * 16 + digit));
+        } else {
+            const bool tab = ref_kind(op.ref2) == R_MSMTAB;
+            if (tab) digit = B.dig2[(size_t)ref_id(op.ref2) * B.n + i];
+            src2 = resolve_src(G, B, i, op.ref2);
+            if (tab && table_affine) {
+                p2 = jac_from_aff(load_aff_src(B, i, src2));
+                z2one = true;
+            } else {
+                p2 = load_jac_src(B, i, src2, (op.flags & F_Z2ONE) != 0);
+            }
+        }
+        settle(p2.X);
+        settle(p2.Y);
+        settle(p2.Z);
+        settle(digit);
+        if (role == 0) B.src[(size_t)(2 * t + 1) * B.n + i] = (uint16_t)(src2 | (digit != 0 ? SRC_SEL_BIT : 0));
+        if ((op.flags & F_Z1ONE) && z2one)
+            q = jac_add_quad_cv<CV, true, true>(role, p1, false, s1.zz1, p2, st.acc);
+        else if (z2one)
+            q = jac_add_quad_cv<CV, false, true>(role, p1, s1.have_zz1, s1.zz1, p2, st.acc);
+        else if (op.flags & F_Z1ONE)
+            q = jac_add_quad_cv<CV, true, false>(role, p1, false, s1.zz1, p2, st.acc);
+        else
+            q = jac_add_quad_cv<CV, false, false>(role, p1, false, s1.zz1, p2, st.acc);
+        if (op.kind == OP_CADD) {
+            st.dyn_idx = op.cadd_idx;
+            st.dyn_val = digit != 0 ? (uint16_t)t : src1;
+            if (role == 0) B.dyn[(size_t)op.cadd_idx * B.n + i] = st.dyn_val;
+        }
+    }
+    quad_store_op(B, i, role, t, op.flags, q, st.acc);
+    st.acc = q.acc;
+    st.p1 = p1;
+    st.p1_zz = q.zz1;
+    st.p1_id = (op.flags & F_Z1ONE) ? (uint16_t)0xFFFF : src1;
+    st.out = q.res.p;
+    st.out_zz = q.zz3;
+    st.out_id = (uint16_t)t;
+}
+// ops [lo, hi) of a curve program's chain for a quad (its own inversion batch: the prefix starts at one)
+template <class CV>
+P2E_HD void body_chain_range_quad_cv(const Program& G, const Buffers& B, size_t i, int role, int lo, int hi, bool table_affine) {
+    ChainStateQ st;
+    st.out_id = st.p1_id = st.dyn_idx = st.dyn_val = 0xFFFF;
+    st.out.X = st.out.Y = st.out.Z = st.p1.X = st.p1.Y = st.p1.Z = st.out_zz = st.p1_zz = u256_zero();
+    st.acc = u256_small(1);
+    for (int t = lo; t < hi; t++) {
+        const OpDesc op = load_op(B.ops, t);
+        const P1Sel s1 = quad_first_operand(G, B, i, op, st);
+        body_chain_op_quad_cv<CV>(G, B, i, role, t, op, table_affine, s1, st);
+    }
 }
 
 }  // namespace p2e
