@@ -208,7 +208,10 @@ def strong_shape(p2e, torch, dist, args, world, rank, dev, dev_index, backend, c
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
+            ts = time.perf_counter()
             body()
+            if os.environ.get("P2E_BENCH_DEBUG"):
+                print(f"[rank {rank}] {body.__name__}: {(time.perf_counter() - ts) * 1e3:.3f} ms", file=sys.stderr, flush=True)
         barrier()
         t = torch.tensor([(time.perf_counter() - t0) / steps], dtype=torch.float64, device=dev if on_dev else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -431,6 +434,17 @@ def main():
         del g
 
     checked = None
+    if rank == 0 and args.check > 0 and args.compact:
+        # the compact container of THIS run against the oracle: sampled signatures, every column
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_c
+        k = (issued[0] - 1) % depth if issued[0] else 0
+        sample = np.unique(np.linspace(0, n - 1, min(args.check, n, 4096)).astype(np.int64))
+        want, werr, wflags = oracle_c.verify_witness_lockstep(*[a[sample] for a in sigs], nthreads=usable_cores(oracle_c.max_threads()))
+        idx = torch.from_numpy(sample).to(dev)
+        got = p2e.compact_expand(0, nar_bufs[k][:, idx].cpu().numpy().view(np.uint32), wid_bufs[k][:, idx].cpu().numpy())
+        assert np.array_equal(got, want) and not werr.any() and wflags.all(), "GPU compact container differs from the oracle"
+        checked = int(len(sample))
     if rank == 0 and args.check > 0 and not args.compact:
         # bit-exactness of THIS run: sampled signatures of the last output buffer against the C oracle, every column
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -41,7 +41,7 @@ out = {"source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE /
                 "of a 16 B/lane streaming read)", "kernels": {}}
 # the PMC runs use bench.py --steps 2 --warmup 1 : 3 pipeline steps, so per-step sums = total / 3
 STEPS = 3
-for k in ("k_expand_runs", "k_expand", "k_batch_inv", "k_chains", "k_scalar"):
+for k in ("k_expand_runs", "k_expand", "k_expand_fb_run", "k_batch_inv", "k_chains", "k_scalar"):
     f = fetch.get(k, [])
     w = write.get(k, [])
     if not f and not w:
