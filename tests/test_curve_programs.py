@@ -533,13 +533,20 @@ def _blind_of(cv, rng):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("plan", ["four_lanes", "lane_per_signature"])
 @pytest.mark.parametrize("name", PROGRAMS)
-def test_gpu_ragged_batch_against_the_c_oracle_and_the_walk(name, gpu, emu):
+def test_gpu_ragged_batch_against_the_c_oracle_and_the_walk(name, plan, gpu, emu, monkeypatch):
     """300 random inputs (one full workgroup of paired stores + a ragged tail): every column of every input against the
     independent C oracle (oracle/p2e_oracle.c: the reference's affine formulas, Knuth D, Fermat inverses -- no code shared
-    with the kernels), three of them against the big-int walk as well"""
+    with the kernels), three of them against the big-int walk as well.  Both small-batch forms of phases A / B: four lanes
+    per signature with split inversion batches (what n <= 14 336 takes since round 3) and one lane per signature (what
+    14 336 < n < 49 152 takes), each op expanded on its own."""
     import oracle_c
     p2e, torch, ctx = gpu
+    if plan == "lane_per_signature":
+        monkeypatch.setenv("P2E_QUAD_MAX_N", "0")
+        ctx = p2e.Context(device=0)
+        gpu = (p2e, torch, ctx)
     m = META[name]
     cv = CURVES[m["curve"]]
     blind_i, blind = _blind_of(cv, R.SplitMix64(1234 + m["kind"] + 10 * m["curve"]))
