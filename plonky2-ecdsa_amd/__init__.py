@@ -132,12 +132,17 @@ def lib():
         except ImportError:
             pass
         _lib = C.CDLL(LIB_PATH)
+        experimental = bool(os.environ.get("P2E_LIB"))   # an A/B build under tools/ may predate newer entry points
         for name in EXPORTS:
+            if experimental and not hasattr(_lib, name):
+                continue
             getattr(_lib, name)  # AttributeError if a declared symbol is not exported
         _lib.p2e_last_error.restype = C.c_char_p
         _lib.p2e_scratch_bytes.restype = C.c_size_t
         _lib.p2e_scratch_bytes.argtypes = [C.c_int, C.c_size_t]
         for name in EXPORTS:
+            if experimental and not hasattr(_lib, name):
+                continue
             if name.endswith("_batch") or name in ("p2e_limb_split", "p2e_limb_pack", "p2e_columns_to_rows", "p2e_schedule_describe",
                                                    "p2e_schedule_num_cols", "p2e_aux_describe", "p2e_aux_num_cols", "p2e_compact_layout",
                                                    "p2e_columns_compact", "p2e_compact_to_rows", "p2e_curve_program_num_cols",
