@@ -288,7 +288,7 @@ def assemble_fill(ctx, asm: ColumnAssembly, issue, compact_map=None, host_stage=
                         ctx.segment_sync(k)
                 if st is None:
                     for j in range(len(rows)):
-                        asm.local_view(j).copy_(host_stage[j])
+                        asm.local_view(j)[:, :asm.n_local].copy_(host_stage[j][:, :asm.n_local])
             asm.exchange([(0, r) for r in rows], ready=ready_all)
             asm.wait()
             return segs
@@ -306,7 +306,8 @@ def assemble_fill(ctx, asm: ColumnAssembly, issue, compact_map=None, host_stage=
                 for j, blk in enumerate(blocks):
                     if blk and blk[1]:
                         r0, nr = blk
-                        asm.local_view(j)[r0:r0 + nr].copy_(host_stage[j][r0:r0 + nr])
+                        # (only the shard's own signatures: the pad column of a shorter shard stays zero)
+                        asm.local_view(j)[r0:r0 + nr, :asm.n_local].copy_(host_stage[j][r0:r0 + nr, :asm.n_local])
             asm.exchange(blocks, ready=ready)
     asm.wait()
     return segs

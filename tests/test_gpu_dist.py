@@ -63,7 +63,10 @@ def _worker(rank, world, port, total, compact, q):
             ctx.ecdsa_verify_witness_batch(*dev, cols=stage[0][:, :n], err=err, valid=valid, ld=ld)
 
     segs = pd.assemble_fill(ctx, asm, issue, compact_map=cmap, host_stage=stage)
+    why = []
     ok = ctx.sync() == 0 and int(valid.sum()) == n and len(segs) >= 6
+    if not ok:
+        why.append(f"fill: valid {int(valid.sum())} of {n}, {len(segs)} blocks")
     if rank == 0:
         want, werr, wflags = oracle_c.verify_witness_lockstep(*p2e.synth_signatures(seed=23, n=total))
         ok = ok and not werr.any() and wflags.all()
@@ -73,13 +76,17 @@ def _worker(rank, world, port, total, compact, q):
                 got = p2e.compact_expand(0, mats[0][r, :, :e_ - s_].numpy().view(np.uint32), mats[1][r, :, :e_ - s_].numpy())
             else:
                 got = mats[0][r, :, :e_ - s_].numpy().view(np.uint64)
-            ok = ok and np.array_equal(got, want[:, s_:e_])
-            if e_ - s_ < n_max:
-                ok = ok and all(bool((m[r, :, e_ - s_:n_max] == 0).all()) for m in mats)    # the shorter shard's pad column
+            if not np.array_equal(got, want[:, s_:e_]):
+                bad_cols = np.nonzero((got != want[:, s_:e_]).any(axis=1))[0]
+                why.append(f"shard of rank {r}: {len(bad_cols)} columns differ, first {bad_cols[:5]}")
+                ok = False
+            if e_ - s_ < n_max and not all(bool((m[r, :, e_ - s_:n_max] == 0).all()) for m in mats):
+                why.append(f"pad column of rank {r}'s shorter shard is not zero")       # the shorter shard's pad column
+                ok = False
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()
-    q.put((rank, bool(ok)))
+    q.put((rank, bool(ok), "; ".join(why)))
 
 
 @pytest.mark.timeout(600)
@@ -96,4 +103,4 @@ def test_two_ranks_assemble_their_shards_block_by_block(compact):
     for p in procs:
         p.join(400)
     res = sorted(q.get(timeout=10) for _ in range(world))
-    assert res == [(0, True), (1, True)] and all(p.exitcode == 0 for p in procs)
+    assert res == [(0, True, ""), (1, True, "")] and all(p.exitcode == 0 for p in procs)
