@@ -224,11 +224,13 @@ def strong_shape(p2e, torch, dist, args, world, rank, dev, dev_index, backend, c
     def fill_and_assemble():
         segs = assemble_fill(ctx, asm, issue, compact_map=cmap, host_stage=None if on_dev else stage)
         assert ctx.sync() == 0
+        torch.cuda.current_stream().synchronize()       # ... and the exchange (asm.wait() made this stream wait for it)
         return segs
 
     def assemble_only():                       # every block final already: ONE grouped exchange of the whole matrices
         asm.exchange([(0, m.shape[1]) for m in mats])
         asm.wait()
+        torch.cuda.current_stream().synchronize()
 
     t_fill = fill_ms_known / 1e3 if fill_ms_known else timed(fill_only)
     segs = fill_and_assemble()

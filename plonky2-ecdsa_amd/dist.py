@@ -272,11 +272,13 @@ def assemble_fill(ctx, asm: ColumnAssembly, issue, compact_map=None, host_stage=
     # every rank must post the same sequence of blocks.  The block list follows the launch plan, which the library picks
     # by batch size: shards that straddle a plan threshold (sizes differ by one) may disagree -- then the whole matrix
     # goes as ONE block behind the last event (a 12-byte agreement per fill, on the host)
-    if asm.world > 1:
-        mine = [tuple(x) for x in segs]
+    mine = [tuple(x) for x in segs]
+    if asm.world > 1 and getattr(asm, "_agreed_blocks", None) != mine:      # (agreed once per assembly and block list)
         everyone = [None] * asm.world
         dist.all_gather_object(everyone, mine, group=asm.group)
-        if any(e != mine for e in everyone):
+        if all(e == mine for e in everyone):
+            asm._agreed_blocks = mine
+        else:
             rows = [m.shape[1] for m in asm.matrices]
             last = len(segs) - 1
 
