@@ -174,6 +174,22 @@ def verify_witness_lockstep(msg, r, s, pkx, pky, nthreads=0, group=64):
     return cols, err, flags
 
 
+def verify_witness_aux_lockstep(msg, r, s, pkx, pky, nthreads=0, group=64):
+    """(cols, aux, err, flags) by the lock-step walk: hot-path columns plus the built-in-generator values."""
+    arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (msg, r, s, pkx, pky)]
+    n = arrs[0].shape[0]
+    cols, aux = _cols(VERIFY_COLS, n), _cols(VERIFY_AUX, n)
+    err = np.zeros(n, dtype=np.uint8)
+    flags = np.zeros(n, dtype=np.uint8)
+    f = lib().p2e_oracle_verify_witness_aux_lockstep
+    f.restype = C.c_long
+    rc = f(*[_p(a) for a in arrs], _p(cols), C.c_size_t(n), C.c_size_t(n), _p(aux), C.c_size_t(n), _p(err), _p(flags),
+           C.c_int(nthreads), C.c_int(group))
+    if rc < 0:
+        raise MemoryError("p2e_oracle_verify_witness_aux_lockstep: coroutine stacks")
+    return cols, aux, err, flags
+
+
 def glv_mul_witness(px, py, k, nthreads=0):
     arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (px, py, k)]
     n = arrs[0].shape[0]

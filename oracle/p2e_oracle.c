@@ -1456,6 +1456,13 @@ long p2e_oracle_verify_witness_lockstep(const uint8_t *msg, const uint8_t *r, co
     oracle_init();
     return run_lockstep(NULL, msg, r, s, pkx, pky, cols, n, ld, NULL, 0, err, flags, nthreads, group);
 }
+/* the lock-step walk recording the built-in-generator values as well (aux[8959][n], as p2e_oracle_verify_witness_aux) */
+long p2e_oracle_verify_witness_aux_lockstep(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
+                                            const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint64_t *aux, size_t ald,
+                                            uint8_t *err, uint8_t *flags, int nthreads, int group) {
+    oracle_init();
+    return run_lockstep(NULL, msg, r, s, pkx, pky, cols, n, ld, aux, ald, err, flags, nthreads, group);
+}
 static int cp_job_init(cp_job *J, int kind, int curve, const uint8_t *bx, const uint8_t *by) {
     if (kind < 1 || kind > 3 || curve < 0 || curve > 1 || (kind == P2E_O_CP_VERIFY && curve != 1) || !bx || !by) return -1;
     oracle_init();

@@ -82,6 +82,10 @@ long p2e_oracle_verify_witness(const uint8_t *msg, const uint8_t *r, const uint8
 long p2e_oracle_verify_witness_lockstep(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
                                         const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint8_t *err,
                                         uint8_t *flags, int nthreads, int group);
+/* ... additionally recording aux[8959][n] (see p2e_oracle_verify_witness_aux below); aux == NULL: not recorded */
+long p2e_oracle_verify_witness_aux_lockstep(const uint8_t *msg, const uint8_t *r, const uint8_t *s, const uint8_t *pkx,
+                                            const uint8_t *pky, uint64_t *cols, size_t n, size_t ld, uint64_t *aux, size_t ald,
+                                            uint8_t *err, uint8_t *flags, int nthreads, int group);
 /* gadgets/glv.rs:87-104 : cols[65243][n] */
 long p2e_oracle_glv_mul_witness(const uint8_t *px, const uint8_t *py, const uint8_t *k, uint64_t *cols,
                                 size_t n, size_t ld, uint8_t *err, uint8_t *flags, int nthreads);
