@@ -72,8 +72,12 @@ typedef struct p2e_ctx p2e_ctx;
 /* `stream`: a hipStream_t to run on (e.g. torch's current stream), or NULL for a library-owned one.  The
  * library-owned stream is a blocking stream (hipStreamDefault): work the caller queued on the legacy default
  * stream before a call is ordered before it, and default-stream work queued after a call is ordered after it.
- * The fused entry points use two more internal streams; export GPU_MAX_HW_QUEUES=8 before the process's first
- * HIP call so that they do not share a hardware queue with the caller's streams. */
+ * The fused entry points dispatch on five internal streams (two chain streams, a second inversion stream, two
+ * expansion streams) which the context creates -- and binds to their hardware queues with one empty launch each --
+ * back to back, in a fixed order; `stream` itself carries only the scalar phase and the finalisation of a fused call and
+ * is ordered with the internal streams by events, so the call behaves like any other work queued on `stream`.  Creating
+ * a context synchronises the legacy default stream once.  Export GPU_MAX_HW_QUEUES=8 before the process's first HIP call
+ * so that the internal streams do not share a hardware queue with the caller's. */
 int p2e_ctx_create(int device, unsigned flags, void *stream, p2e_ctx **out);
 void p2e_ctx_destroy(p2e_ctx *ctx);
 int p2e_sync(p2e_ctx *ctx);

@@ -841,10 +841,12 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     // string: M / F / B = the two chain streams and the second inversion stream (high priority), 2 = the second expansion
     // stream of the small-batch plan (low priority), 1 = an own first expansion stream (normal priority; without it the
     // caller's stream carries the expansions), P = a spare stream.  HIP binds a hardware queue to a stream at its first
-    // launch and hands queues out in that order; queues that end up as neighbours on a hardware pipe delay each other's
-    // dispatch while one of them sits at a dependency barrier (profiles/r03_stream_order_*: the +-20 % "creation order"
-    // effect of round 2 is the caller's queue landing on the pipe of st_c2 or st_binv).  With every stream the pipeline
-    // dispatches on created here, back to back, their relative placement no longer depends on what the caller did first.
+    // launch and hands queues out in that order, and the step time of the small and mid-size plans depends on WHICH queues
+    // the expansion, chain and inversion streams get relative to each other (profiles/r03_stream_order_*: the +-20 %
+    // "creation order" effect of round 2 goes with the caller's queue sitting four positions from st_c2 in one order and
+    // from st_binv in the other -- consistent with queues sharing a hardware pipe delaying each other's dispatch, though
+    // the pipe assignment itself is not visible from here).  With every stream the pipeline dispatches on created here,
+    // back to back, their relative placement no longer depends on what the caller did first.
     {
         const char* layout = getenv("P2E_STREAM_LAYOUT");
         // default: chain stream, OWN expansion stream, second chain stream, second inversion stream, second expansion
