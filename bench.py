@@ -484,7 +484,10 @@ def main():
             wid_bufs.clear()
         cols = None
         torch.cuda.empty_cache()
-        strong = strong_shape(p2e, torch, dist, args, world, rank, dev, dev_index, backend, args.compact, fill_ms_known=keep_ms)
+        try:
+            strong = strong_shape(p2e, torch, dist, args, world, rank, dev, dev_index, backend, args.compact, fill_ms_known=keep_ms)
+        except Exception as e:      # the headline line (the timed region above) must survive this leg
+            strong = {"error": f"{type(e).__name__}: {e}"}
 
     limb_split = None
     if rank == 0 and not args.no_limb_split:
@@ -578,7 +581,7 @@ def main():
             line["allgather"] = gather
         if strong:
             line["strong"] = strong
-            if args.scaling == "strong":
+            if args.scaling == "strong" and "value_with_allgather" in strong:
                 line["value_with_allgather"] = strong["value_with_allgather"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["cpu_baseline_optimised"] = cpu_baseline(p2e, seed=4)
