@@ -1558,9 +1558,14 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         if (groups > nruns) groups = nruns;
         // small-batch plan: an explicit list of runs per piece (the list is used while it fits; the last piece takes the rest)
         int listed = 0;
-        if (quad && c->small_takes[0] > 0) {
+        // default list for the runs of 4 iterations (19 runs): 6, 5, 5, 2 and the last run alone -- the last piece's inversion
+        // batch and expansion are the exposed tail of the call (2.27 / 2.92 against 2.32 / 2.98 ms at 2^13 / 12 288 with
+        // equal pieces, profiles/r03_quad_plan_piece_sizes_sweep.txt)
+        static const int takes_r4[p2e_ctx::MAX_PIECES + 1] = {6, 5, 5, 2, 0};
+        const int* takes = c->small_takes[0] > 0 ? c->small_takes : (quad && run_iters == 4 && iters == MSM_DIGITS) ? takes_r4 : c->small_takes;
+        if (quad && takes[0] > 0) {
             int sum = 0;
-            while (listed < p2e_ctx::MAX_PIECES - 1 && c->small_takes[listed] > 0 && sum + c->small_takes[listed] < nruns) sum += c->small_takes[listed++];
+            while (listed < p2e_ctx::MAX_PIECES - 1 && takes[listed] > 0 && sum + takes[listed] < nruns) sum += takes[listed++];
             groups = listed + 1;
         }
         segs[ns++] = Seg{lo0, lb, lb - lo0, c->st_msm, false, lo0, lb, 0, 0, false};
@@ -1568,7 +1573,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         for (int g = 0; g < groups; g++) {
             int rem = groups - g;
             int take = (nruns - run + rem - 1) / rem;
-            if (listed) take = g < listed ? c->small_takes[g] : nruns - run;
+            if (listed) take = g < listed ? takes[g] : nruns - run;
             int it0 = run * R, it1 = (run + take) * R < iters ? (run + take) * R : iters;
             Seg sg{lb + 3 * it0, lb + 3 * it1, lb + 3 * it1 - lo0, c->st_msm, false, 0, 0, it0, it1, false};
             if (run_iters == 0) {   // no run expansion: op by op
