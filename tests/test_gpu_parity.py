@@ -865,3 +865,25 @@ def test_column_blocks_are_final_when_their_event_fires(monkeypatch, plan):
     with pytest.raises(p2e.P2EError):
         ctx.segment_sync(len(segs2))
     ctx.close()
+
+
+@pytest.mark.parametrize("layout", ["MFB2", "2P1BFM"])
+def test_other_stream_layouts_give_the_same_witness(ora, monkeypatch, layout):
+    """P2E_STREAM_LAYOUT (csrc/p2e_hip.hip p2e_ctx_create): the creation / queue-binding order of the library's streams, with
+    ("1") or without an own first expansion stream (without: the round-2 form, expansions on the caller's stream), spare
+    streams ("P").  A tuning knob -- whatever it is set to, every plan must produce the oracle's matrix."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    monkeypatch.setenv("P2E_STREAM_LAYOUT", layout)
+    ctx = p2e.Context(device=0)
+    for n, env in ((700, None), (700, ("P2E_QUAD_MAX_N", "0"))):
+        if env:
+            monkeypatch.setenv(*env)
+            ctx = p2e.Context(device=0)
+        sigs = p2e.synth_signatures(seed=123, n=n)
+        dev = [torch.from_numpy(a).cuda() for a in sigs]
+        cols, err, valid, bad = ctx.ecdsa_verify_witness_batch(*dev)
+        torch.cuda.synchronize()
+        want, _, wflags = ora.verify(*sigs)
+        assert bad == 0 and np.array_equal(cols.cpu().numpy().view(np.uint64), want) and np.array_equal(valid.cpu().numpy(), wflags)
+        assert len(ctx.segments()) >= 6
