@@ -836,6 +836,44 @@ def test_gpu_p256_verify_batch_properties(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("plan", ["four_lanes", "lane_per_signature"])
+def test_gpu_edge_inputs_of_the_curve_programs(plan, monkeypatch):
+    """Where the reference panics the kernels must flag the element and leave its neighbours alone, in both small-batch
+    plans: scalar 0 (the unblinding add inverts zero), the caller's point equal to the circuit's blinding point or its
+    negative (precompute_window adds a point to itself / its negative); scalars above the group order and a non-canonical
+    point coordinate are legal.  Error bytes against the C oracle on every element, columns on every element it does not flag."""
+    import oracle_c
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    if plan == "lane_per_signature":
+        monkeypatch.setenv("P2E_QUAD_MAX_N", "0")
+    ctx = p2e.Context(device=0)
+    rng = R.SplitMix64(2718)
+    arr = lambda vs: np.stack([np.frombuffer(int(v).to_bytes(32, "little"), np.uint8).copy() for v in vs])
+    for ci, cv in enumerate(CURVES):
+        blind_i, blind = _blind_of(cv, rng)
+        good = [cv.mul(rng.below(cv.n), cv.g) for _ in range(70)]
+        pts = list(good)
+        ks = [rng.below(cv.n) for _ in pts]
+        ks[3], ks[40], ks[69] = 0, cv.n + 5, (1 << 256) - 1
+        pts[10], pts[64] = blind_i, cv.neg(blind_i)
+        xs = [p[0] for p in pts]
+        if xs[20] + cv.p < 1 << 256:
+            xs[20] += cv.p                                      # same field element, raw limbs differ (quirk Q3)
+        args = (arr(xs), arr([p[1] for p in pts]), arr(ks))
+        for kind in (p2e.CP_WINDOWED_MUL, p2e.CP_SCALAR_MUL):
+            prog, (cols, err, valid, bad) = _gpu_run((p2e, torch, ctx), kind, ci, blind_i, args)
+            ocols, _a, oerr, _f = oracle_c.curve_program(kind, ci, blind, args, want_aux=False)
+            assert np.array_equal(err, oerr) and bad == int((oerr != 0).sum()), (cv.name, kind)
+            assert oerr[3] & R.ERR_INVERSE_OF_ZERO and oerr[0] == 0 and oerr[40] == 0 and oerr[69] == 0 and oerr[20] == 0
+            if kind == p2e.CP_WINDOWED_MUL:
+                assert oerr[10] and oerr[64]
+            clean = oerr == 0
+            assert np.array_equal(cols[:, clean], ocols[:, clean]), (cv.name, kind)
+            prog.close()
+
+
+@pytest.mark.gpu
 def test_gpu_curve_program_misuse(gpu):
     p2e, torch, ctx = gpu
     with pytest.raises(p2e.P2EError):
