@@ -539,8 +539,8 @@ def test_gpu_ragged_batch_against_the_c_oracle_and_the_walk(name, plan, gpu, emu
     """300 random inputs (one full workgroup of paired stores + a ragged tail): every column of every input against the
     independent C oracle (oracle/p2e_oracle.c: the reference's affine formulas, Knuth D, Fermat inverses -- no code shared
     with the kernels), three of them against the big-int walk as well.  Both small-batch forms of phases A / B: four lanes
-    per signature with split inversion batches (what n <= 14 336 takes since round 3) and one lane per signature (what
-    14 336 < n < 49 152 takes), each op expanded on its own."""
+    per signature with split inversion batches (what n <= 17 408 takes since round 3) and one lane per signature (what
+    17 408 < n < 49 152 takes), each op expanded on its own."""
     import oracle_c
     p2e, torch, ctx = gpu
     if plan == "lane_per_signature":
