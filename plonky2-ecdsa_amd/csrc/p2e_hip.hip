@@ -590,6 +590,11 @@ struct p2e_ctx {
     // piece's inversion batch (latency matters there; the earlier ones only need throughput: fewer inversions).
     int small_takes[p2e_ctx::MAX_PIECES + 1] = {0};
     int binv_split_log2_last = 3;
+    // small-batch plan: which of the two phase-B streams takes the FIRST batch after the window table's (the fixed-base
+    // chain's).  1: the fixed-base chain's own stream -- the table's batch occupies the other one until ~0.7 ms, and the
+    // fixed-base batch (67 ops that all keep their affine form: the longest) queued behind it used to hold up the second
+    // loop piece's batch in turn.  0: the round-2 order.
+    int quad_b_first_on_fixed = 1;
     unsigned expand_lds_small = 160000;
     unsigned expand_lds = 0;   // the same knob for the large-batch plan
     Aff* d_cpts = nullptr;
@@ -780,6 +785,7 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         if (c->expand_lds_small > (unsigned)max_lds) c->expand_lds_small = (unsigned)max_lds;
         if (c->expand_lds > (unsigned)max_lds) c->expand_lds = (unsigned)max_lds;
     }
+    if (const char* env = getenv("P2E_QUAD_B_FIRST_ON_FIXED")) c->quad_b_first_on_fixed = atoi(env) != 0;
     if (const char* env = getenv("P2E_BINV_SPLIT_LOG2_LAST")) {
         int v = atoi(env);
         if (v >= 0 && v <= 4) c->binv_split_log2_last = v;
@@ -1687,7 +1693,8 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         // with C.  The fixed-base chain's stream is idle after its first ~1 ms, so phase B lives there.
         // (small-batch plan: phase B of consecutive pieces alternates between two streams, so that an inversion batch
         // does not queue behind the previous one -- there the chains are no slower than phase B)
-        hipStream_t st_b = (alt_b && (q & 1)) ? c->st_binv : c->st_fixed;
+        const bool b_odd = (q & 1) != (quad && c->quad_b_first_on_fixed ? 1 : 0);
+        hipStream_t st_b = (alt_b && b_odd) ? c->st_binv : c->st_fixed;
         if (k != first_msm) {
             HIP_TRY(hipStreamWaitEvent(st_b, c->ev_piece[k], 0));
             launch_binv(st_b, sg.lo, sg.hi, 1, k == ns - 1);

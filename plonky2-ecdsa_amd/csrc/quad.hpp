@@ -17,6 +17,7 @@
 // S in flight at once): body_batch_inv_split.
 #pragma once
 #include "pipeline.hpp"
+#include "quad29.hpp"
 
 namespace p2e {
 
@@ -281,6 +282,22 @@ P2E_HD void quad_store_op(const Buffers& B, size_t i, int role, int t, uint8_t f
     if (q.z3_zero) err_or(&B.err[i], ERR_INVERSE_OF_ZERO);   // reference: inverse() of zero panics (gadgets/nonnative.rs:863)
 }
 
+// The same for an op computed on lazy limbs (quad29.hpp): every lane stores the ONE value it canonicalised (role 0 X3 --
+// Z3 again for F_NO_AFFINE --, 1 the prefix product before the op, 2 Z3, 3 W); Y3 exists only after the op's last level
+// and is converted here for the ops that need their affine form (the flag is wave-uniform).
+P2E_HD void quad_store_op29(const Buffers& B, size_t i, int role, int t, uint8_t flags, const QuadRes29& q) {
+    const size_t o = (size_t)t * B.n + i;
+    const bool no_affine = (flags & F_NO_AFFINE) != 0;
+    uintptr_t bx = (uintptr_t)B.PX, bp = (uintptr_t)B.PREF, bz = (uintptr_t)B.PZ, bw = (uintptr_t)B.PW;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(bx), "+s"(bp), "+s"(bz), "+s"(bw));
+#endif
+    U256* const dst = (U256*)(role == 1 ? bp : role == 3 ? bw : (role == 0 && !no_affine) ? bx : bz);
+    dst[o] = q.mine;
+    if (!no_affine) B.PY[o] = f29_canon(q.p.Y);
+    if (q.z3_zero) err_or(&B.err[i], ERR_INVERSE_OF_ZERO);   // reference: inverse() of zero panics (gadgets/nonnative.rs:863)
+}
+
 // first operand of op `op`: from the registers of the previous ops whenever the schedule allows (310 of 311 ops),
 // from scratch otherwise (the first op of a chain piece)
 struct P1Sel {
@@ -436,6 +453,9 @@ P2E_HD void body_msm_iters_quad(const Program& G, const Buffers& B, size_t i, in
     settle(p2_cur.X);
     settle(p2_cur.Y);
     settle(p2_cur.Z);
+    // the running point, Z^2 of it and the prefix product live on lazy limbs inside the loop (quad29.hpp)
+    JacL c = jacl_from(cur);
+    F29 c_zz = f29_from_u256(cur_zz), a29 = f29_from_u256(acc);
     for (int it = it0; it < it1; it++) {
         const int t = lb + 3 * it;
         // ---- loads of this iteration, all up front
@@ -444,36 +464,39 @@ P2E_HD void body_msm_iters_quad(const Program& G, const Buffers& B, size_t i, in
         const OpDesc o0 = load_op(B.ops, t), o1 = load_op(B.ops, t + 1), o2 = load_op(B.ops, t + 2);
         // ---- double, double
         for (int k = 0; k < 2; k++) {
-            const U256 acc_before = acc;
-            const QuadRes q = jac_dbl_quad(role, cur, acc);
+            const uint8_t fl = k ? o1.flags : o0.flags;
+            const QuadRes29 q = jac_dbl_quad29(role, (fl & F_NO_AFFINE) != 0, c, a29);
             B.src[(size_t)(2 * (t + k)) * B.n + i] = cur_id;   // (all four lanes: same value)
-            quad_store_op(B, i, role, t + k, k ? o1.flags : o0.flags, q, acc_before);
-            acc = q.acc;
-            cur = q.res.p;
-            cur_zz = q.zz3;
+            quad_store_op29(B, i, role, t + k, fl, q);
+            a29 = q.acc;
+            c = q.p;
+            c_zz = q.zz3;
             cur_id = (uint16_t)(t + k);
         }
         // ---- conditional add of the selected table entry (the sum is always computed: quirk Q7)
-        const U256 acc_before = acc;
-        const QuadRes q = TA ? jac_add_quad<false, true>(role, cur, true, cur_zz, p2_cur, acc)
-                             : jac_add_quad<false, false>(role, cur, false, cur_zz, p2_cur, acc);
+        const JacL p2 = jacl_from(p2_cur);
+        const QuadRes29 q = TA ? jac_add_quad29<false, true>(role, (o2.flags & F_NO_AFFINE) != 0, c, true, c_zz, p2, a29)
+                               : jac_add_quad29<false, false>(role, (o2.flags & F_NO_AFFINE) != 0, c, false, c_zz, p2, a29);
         const bool take = s_cur.digit != 0;
         dyn_idx = o2.cadd_idx;
         dyn_val = take ? (uint16_t)(t + 2) : cur_id;
         B.src[(size_t)(2 * (t + 2)) * B.n + i] = cur_id;
         B.src[(size_t)(2 * (t + 2) + 1) * B.n + i] = (uint16_t)(s_cur.src | (take ? SRC_SEL_BIT : 0));
         B.dyn[(size_t)o2.cadd_idx * B.n + i] = dyn_val;
-        quad_store_op(B, i, role, t + 2, o2.flags, q, acc_before);
-        acc = q.acc;
-        cur.X = u256_select(take, q.res.p.X, cur.X);
-        cur.Y = u256_select(take, q.res.p.Y, cur.Y);
-        cur.Z = u256_select(take, q.res.p.Z, cur.Z);
-        cur_zz = u256_select(take, q.zz3, q.zz1);
+        quad_store_op29(B, i, role, t + 2, o2.flags, q);
+        a29 = q.acc;
+        c.X = f29_select(take, q.p.X, c.X);
+        c.Y = f29_select(take, q.p.Y, c.Y);
+        c.Z = f29_select(take, q.p.Z, c.Z);
+        c_zz = f29_select(take, q.zz3, q.zz1);
         cur_id = dyn_val;
         s_cur = s_nxt;
         s_nxt = s_n2;
         p2_cur = p2_nxt;
     }
+    cur = jacl_canon(c);
+    cur_zz = f29_canon(c_zz);
+    acc = f29_canon(a29);
 }
 // fixed-base windows [t0, t0 + count): one conditional add of fbtab[window][digit] each (gadgets/curve_fixed_base.rs:43-62)
 P2E_HD void body_fb_windows_quad(const Buffers& B, size_t i, int role, int t0, int count, Jac& cur, uint16_t& cur_id, U256& acc,
@@ -487,30 +510,38 @@ P2E_HD void body_fb_windows_quad(const Buffers& B, size_t i, int role, int t0, i
     settle(d_nxt);
     settle(p2_cur.x);
     settle(p2_cur.y);
+    JacL c = jacl_from(cur);
+    F29 c_zz = f29_from_u256(cur_zz), a29 = f29_from_u256(acc);
     for (int t = t0; t < t1; t++) {
         const u32 d_n2 = digit_of_op(t + 2);
         const Aff p2_nxt = B.fbtab[window_of(t + 1) * 16 + d_nxt];
         const OpDesc o = load_op(B.ops, t);
-        const U256 acc_before = acc;
-        const QuadRes q = jac_add_quad<false, true>(role, cur, have_zz, cur_zz, jac_from_aff(p2_cur), acc);
+        JacL p2;
+        p2.X = f29_from_u256(p2_cur.x);
+        p2.Y = f29_from_u256(p2_cur.y);
+        p2.Z = f29_small(1);
+        const QuadRes29 q = jac_add_quad29<false, true>(role, (o.flags & F_NO_AFFINE) != 0, c, have_zz, c_zz, p2, a29);
         const bool take = d_cur != 0;
         dyn_idx = o.cadd_idx;
         dyn_val = take ? (uint16_t)t : cur_id;
         B.src[(size_t)(2 * t) * B.n + i] = cur_id;
         B.src[(size_t)(2 * t + 1) * B.n + i] = (uint16_t)(SRC_FB_BIT | (ref_id(o.ref2) * 16 + d_cur) | (take ? SRC_SEL_BIT : 0));
         B.dyn[(size_t)o.cadd_idx * B.n + i] = dyn_val;
-        quad_store_op(B, i, role, t, o.flags, q, acc_before);
-        acc = q.acc;
-        cur.X = u256_select(take, q.res.p.X, cur.X);
-        cur.Y = u256_select(take, q.res.p.Y, cur.Y);
-        cur.Z = u256_select(take, q.res.p.Z, cur.Z);
-        cur_zz = u256_select(take, q.zz3, q.zz1);
+        quad_store_op29(B, i, role, t, o.flags, q);
+        a29 = q.acc;
+        c.X = f29_select(take, q.p.X, c.X);
+        c.Y = f29_select(take, q.p.Y, c.Y);
+        c.Z = f29_select(take, q.p.Z, c.Z);
+        c_zz = f29_select(take, q.zz3, q.zz1);
         have_zz = true;
         cur_id = dyn_val;
         d_cur = d_nxt;
         d_nxt = d_n2;
         p2_cur = p2_nxt;
     }
+    cur = jacl_canon(c);
+    cur_zz = f29_canon(c_zz);
+    acc = f29_canon(a29);
 }
 
 // ops [lo, hi) of one chain for a quad: the two loops above wherever the range contains them, the generic op for
@@ -568,13 +599,85 @@ P2E_HD void body_chain_range_quad(const Program& G, const Buffers& B, size_t i, 
 // Phase B of ops [t0, t1) with the backward pass cut into S sub-ranges; this lane walks sub-range q.  With phase A's
 // cumulative prefix products (have_prefix) a sub-range starts from the inverse of the product THROUGH its last op,
 // which is one inversion of its own: S inversions run side by side instead of one followed by a t1 - t0 long walk.
+// body_batch_inv (pipeline.hpp) for secp256k1 on lazy limbs (fe29.hpp), lanes of a wave walking different ops: the same
+// products in the same order -- v^-1 = W * (inv * prefix), inv *= Z, and for the ops that keep an affine form
+// X * zi^2, Y * zi^3 -- with three differences that only change the time: the multiplications are fe29's, a value is
+// made canonical only where it is stored, and the inputs of op t - 1 are requested before op t is computed (the loop
+// as written in pipeline.hpp exposes one memory round trip per op to a wave that has nothing else to do).
+// The loads are unconditional (an op without an affine form reads its Z twice more instead of X and Y: a load inside a
+// divergent branch drags its wait to the join).
+P2E_HD void body_batch_inv29(const Buffers& B, size_t i, int t0, int t1, bool have_prefix) {
+    U256 accw;
+    if (have_prefix) {
+        accw = range_product<Secp256k1>(B, i, t1 - 1);
+    } else {
+        F29 acc = f29_small(1);
+        for (int t = t0; t < t1; t++) {
+            const size_t o = (size_t)t * B.n + i;
+            U256 z = B.PZ[o];
+            if (u256_is_zero(z)) z = u256_small(1);   // flagged by phase A
+            B.PREF[o] = f29_canon(acc);
+            acc = f29_mul(acc, f29_from_u256(z));
+        }
+        accw = f29_canon(acc);
+    }
+    F29 inv = f29_from_u256(fe_inv<ModP>(accw));
+    struct In {
+        U256 z, pref, w, x, y;
+        uint8_t flags;
+    };
+    auto flags_of = [&](int t) { return B.ops[t < t0 ? t0 : t].flags; };
+    auto fetch = [&](int t, uint8_t fl) {
+        In r;
+        const size_t o = (size_t)(t < t0 ? t0 : t) * B.n + i;
+        const bool aff = !(fl & F_NO_AFFINE);
+        r.z = B.PZ[o];
+        r.pref = B.PREF[o];
+        r.w = B.PW[o];
+        r.x = *(aff ? &B.PX[o] : &B.PZ[o]);
+        r.y = *(aff ? &B.PY[o] : &B.PZ[o]);
+        r.flags = fl;
+        return r;
+    };
+    uint8_t f_nxt = flags_of(t1 - 2);
+    In cur = fetch(t1 - 1, flags_of(t1 - 1));
+    for (int t = t1 - 1; t >= t0; t--) {
+        const uint8_t f_n2 = flags_of(t - 2);
+        const In nxt = fetch(t - 1, f_nxt);
+        const size_t o = (size_t)t * B.n + i;
+        const U256 z = u256_select(u256_is_zero(cur.z), u256_small(1), cur.z);
+        const F29 zi = f29_mul(inv, f29_from_u256(cur.pref));
+        inv = f29_mul(inv, f29_from_u256(z));
+        B.PW[o] = f29_canon(f29_mul(f29_from_u256(cur.w), zi));   // v^-1 of op t
+        if (!(cur.flags & F_NO_AFFINE)) {
+            const F29 zi2 = f29_sqr(zi);
+            const F29 zi3 = f29_mul(zi2, zi);
+            B.AX[o] = f29_canon(f29_mul(f29_from_u256(cur.x), zi2));
+            B.AY[o] = f29_canon(f29_mul(f29_from_u256(cur.y), zi3));
+        }
+        cur = nxt;
+        f_nxt = f_n2;
+    }
+}
+template <class CV>
+struct LazyLimbs {
+    static constexpr bool available = false;
+};
+template <>
+struct LazyLimbs<Secp256k1> {
+    static constexpr bool available = true;
+};
+
 template <class CV = Secp256k1>
 P2E_HD void body_batch_inv_split(const Program& G, const Buffers& B, size_t i, int t0, int t1, bool have_prefix, int q, int S) {
     const int len = t1 - t0;
     const int a = t0 + (int)(((long long)len * q) / S), b = t0 + (int)(((long long)len * (q + 1)) / S);
     if (a >= b) return;
     // (have_prefix: PREF[t] is the product from the piece's first op, so [a, b) needs no forward pass of its own)
-    body_batch_inv<CV>(G, B, i, a, b, have_prefix, false);   // lanes of one wave walk different ops
+    if (LazyLimbs<CV>::available)
+        body_batch_inv29(B, i, a, b, have_prefix);
+    else
+        body_batch_inv<CV>(G, B, i, a, b, have_prefix, false);   // lanes of one wave walk different ops
 }
 
 // ---- curve programs (curves.hpp): any op list of either curve, four lanes per signature ------------------------------

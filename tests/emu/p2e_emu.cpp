@@ -9,6 +9,7 @@
 #include "../../plonky2-ecdsa_amd/csrc/consts.hpp"
 #include "../../plonky2-ecdsa_amd/csrc/pipeline.hpp"
 #include "../../plonky2-ecdsa_amd/csrc/prims.hpp"
+#include "../../plonky2-ecdsa_amd/csrc/fe29.hpp"
 #include "../../plonky2-ecdsa_amd/csrc/quad.hpp"
 #include "../../plonky2-ecdsa_amd/csrc/schedule.hpp"
 #include "../../plonky2-ecdsa_amd/csrc/curve_program.hpp"
@@ -168,6 +169,76 @@ static long run(int program, const uint8_t* msg, const uint8_t* r, const uint8_t
         bad += err32[i] != 0;
     }
     return bad;
+}
+
+// ---- fe29.hpp (lazy 29-bit limbs) against fe.hpp (canonical words): every operation on patterned and random values,
+// with operands pushed through the lazy forms the chains use (sums, differences, small multiples) before they are used
+static U256 f29_test_value(host::SplitMix64& rng) {
+    U256 x;
+    const unsigned long long sel = rng.next();
+    for (int k = 0; k < 4; k++) {
+        unsigned long long w = rng.next();
+        const unsigned pat = (unsigned)(sel >> (8 * k)) & 7;
+        if (pat == 0) w = 0;
+        if (pat == 1) w = ~0ull;
+        if (pat == 2) w &= 0xFFFFFFFFull;
+        x.w[2 * k] = (u32)w;
+        x.w[2 * k + 1] = (u32)(w >> 32);
+    }
+    const unsigned kind = (unsigned)(sel >> 40) & 15;
+    if (kind == 0) x = u256_zero();
+    if (kind == 1) x = u256_small(1);
+    if (kind == 2 || kind == 3) {   // p - 1, p - small
+        x = u256_zero();
+        x = fe_sub<ModP>(x, u256_small(kind == 2 ? 1 : (u32)(sel >> 48) & 0xFFF));
+    }
+    return fe_canon<ModP>(fe_canon<ModP>(x));   // (two conditional subtractions: any 256-bit pattern -> canonical)
+}
+extern "C" long emu_f29_selftest(unsigned long long seed, size_t n) {
+    long fails = 0;
+#pragma omp parallel for reduction(+ : fails)
+    for (long long i = 0; i < (long long)n; i++) {
+        host::SplitMix64 rng{seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1))};
+        const U256 a = f29_test_value(rng), b = f29_test_value(rng), c = f29_test_value(rng);
+        const F29 fa = f29_from_u256(a), fb = f29_from_u256(b), fc = f29_from_u256(c);
+        auto same = [&](const F29& got, const U256& want) { fails += !u256_eq(f29_canon(f29_norm(got)), want); };
+        auto same_direct = [&](const F29& got, const U256& want) { fails += !u256_eq(f29_canon(got), want); };   // limbs < 2^31
+        typedef ModP F;
+        same(fa, a);
+        same_direct(fa, a);
+        same_direct(f29_mul(fa, fb), fe_mul<F>(a, b));
+        same_direct(f29_sub<1>(fa, fb), fe_sub<F>(a, b));
+        same_direct(f29_add(f29_add(fa, fb), fc), fe_add<F>(fe_add<F>(a, b), c));
+        same(f29_mul(fa, fb), fe_mul<F>(a, b));
+        same(f29_sqr(fa), fe_sqr<F>(a));
+        same(f29_add(fa, fb), fe_add<F>(a, b));
+        same(f29_sub<1>(fa, fb), fe_sub<F>(a, b));
+        same(f29_norm(f29_sub<1>(fa, fb)), fe_sub<F>(a, b));
+        same(f29_times<3>(fa), fe_add<F>(fe_add<F>(a, a), a));
+        // lazy operands: (a + b) (2 c), (a - b)(c - a), (a + b)^2, (a - b - c)^2 normalised first, 4 (a - 2 b)
+        const U256 apb = fe_add<F>(a, b), amb = fe_sub<F>(a, b), cma = fe_sub<F>(c, a), c2 = fe_add<F>(c, c);
+        same(f29_mul(f29_add(fa, fb), f29_times<2>(fc)), fe_mul<F>(apb, c2));
+        same(f29_mul(f29_norm(f29_sub<1>(fa, fb)), f29_sub<1>(fc, fa)), fe_mul<F>(amb, cma));
+        same(f29_sqr(f29_add(fa, fb)), fe_sqr<F>(apb));
+        same(f29_sqr(f29_norm(f29_sub<1>(f29_sub<1>(fa, fb), fc))), fe_sqr<F>(fe_sub<F>(amb, c)));
+        const U256 b2 = fe_add<F>(b, b), am2b = fe_sub<F>(a, b2), am2b2 = fe_add<F>(am2b, am2b);
+        same(f29_times<4>(f29_norm(f29_sub<2>(fa, f29_times<2>(fb)))), fe_add<F>(am2b2, am2b2));
+        same(f29_sub<3>(fa, f29_times<3>(fb)), fe_sub<F>(a, fe_add<F>(b2, b)));
+        same(f29_sub<4>(fa, f29_add(f29_times<3>(fb), fc)), fe_sub<F>(fe_sub<F>(a, fe_add<F>(b2, b)), c));
+        // a chain of dependent operations on lazy values
+        F29 x = fa;
+        U256 y = a;
+        for (int k = 0; k < 6; k++) {
+            x = f29_mul(f29_add(x, fb), f29_sub<1>(x, fc));
+            y = fe_mul<F>(fe_add<F>(y, b), fe_sub<F>(y, c));
+            x = f29_sqr(f29_norm(f29_sub<1>(f29_times<2>(x), fa)));
+            y = fe_sqr<F>(fe_sub<F>(fe_add<F>(y, y), a));
+        }
+        same(x, y);
+        fails += f29_is_zero(f29_sub<1>(fa, fa)) ? 0 : 1;
+        fails += f29_is_zero(f29_mul(f29_sub<1>(fa, fb), f29_norm(f29_sub<1>(fb, fa)))) != u256_eq(a, b) ? 1 : 0;
+    }
+    return fails;
 }
 
 extern "C" {

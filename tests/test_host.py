@@ -211,6 +211,17 @@ def test_batch_inversion_chunking_is_output_invariant(chunk):
     assert not err.any() and valid.all() and np.array_equal(got, want)
 
 
+def test_lazy_limb_field_arithmetic_matches_the_canonical_form():
+    """csrc/fe29.hpp (secp256k1's p on unsaturated 29-bit limbs, what the four-lane chains compute with) against csrc/fe.hpp
+    (canonical 32-bit words): every operation, operands pushed through the lazy forms the chains use, on random and
+    patterned values (0, 1, p - 1, p - small, all-ones words).  The emulation build carries a worst-case bound beside
+    every limb (-DP2E_F29_BOUNDS) and aborts the process if any operation's precondition could be violated."""
+    import ctypes as C
+    L = EmuBackend().L
+    L.emu_f29_selftest.restype = C.c_long
+    assert L.emu_f29_selftest(C.c_ulonglong(7), C.c_size_t(300000)) == 0
+
+
 @pytest.mark.parametrize("split", [1, 4, 5])
 def test_quad_lanes_and_split_inversion_batches_are_output_invariant(split):
     """csrc/quad.hpp (the small-batch plan): the chains walked by four lanes per signature (levels of four
