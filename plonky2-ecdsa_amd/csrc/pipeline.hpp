@@ -11,7 +11,7 @@
 //   C  expand      the 231/282/251 witness columns of every curve op, fully parallel          (1 thread/sig/op)
 // Phase C writes 98% of the output bytes and is the HBM-bound kernel the roofline is quoted on.
 #pragma once
-#include "ec.hpp"
+#include "ec29.hpp"
 #include "wit.hpp"
 
 namespace p2e {
@@ -384,6 +384,86 @@ P2E_HD void body_chain_op(const Program& G, const Buffers& B, size_t i, int t, b
     st.out = res.p;
     st.out_id = (uint16_t)t;
 }
+// body_chain_op for secp256k1 on lazy limbs (ec29.hpp): same operand resolution, same scratch outputs (canonical), the
+// state carried from op to op stays on lazy limbs.
+struct ChainState29 {
+    JacL out, p1;
+    uint16_t out_id, p1_id;
+    F29 acc;
+};
+template <bool GENERIC = false>
+P2E_HD void body_chain_op29(const Program& G, const Buffers& B, size_t i, int t, bool table_affine, ChainState29& st,
+                            const Aff* lds_fb = nullptr, u32 lds_w0 = 0) {
+    const OpDesc op = load_op(B.ops, t);
+    size_t o = (size_t)t * B.n + i;
+    JacWL res;
+    uint16_t src1 = resolve_src(G, B, i, op.ref1);
+    const bool from_out = src1 == st.out_id, from_p1 = src1 == st.p1_id;
+    JacL p1 = st.out;
+    if (!(from_out || from_p1)) p1 = jacl_from(load_jac_src(B, i, src1, (op.flags & F_Z1ONE) != 0));
+    p1 = jacl_select3(from_out, st.out, from_p1, st.p1, p1);
+    B.src[(size_t)(2 * t) * B.n + i] = src1;
+    if (op.kind == OP_DBL) {
+        res = jac_dbl29(p1);
+    } else {
+        Jac p2w;
+        u32 digit = 1;
+        uint16_t src2;
+        bool z2one = (op.flags & F_Z2ONE) != 0;
+        if (GENERIC && ref_kind(op.ref2) == R_SELSLOT) {
+            digit = B.dig2[(size_t)(ref_id(op.ref2) >> 12) * B.n + i];
+            src2 = (uint16_t)(ref_id(op.ref2) & 0xFFFu);
+            p2w = load_jac_src(B, i, src2, z2one);
+        } else if (ref_kind(op.ref2) == R_FBTAB) {
+            Aff a = load_fbtab(B, i, ref_id(op.ref2), digit, lds_fb, lds_w0);
+            p2w = jac_from_aff(a);
+            src2 = (uint16_t)(SRC_FB_BIT | (ref_id(op.ref2) * 16 + digit));
+        } else {
+            const bool tab = ref_kind(op.ref2) == R_MSMTAB;
+            if (tab) digit = B.dig2[(size_t)ref_id(op.ref2) * B.n + i];
+            src2 = resolve_src(G, B, i, op.ref2);
+            if (tab && table_affine) {
+                p2w = jac_from_aff(load_aff_src(B, i, src2));
+                z2one = true;
+            } else {
+                p2w = load_jac_src(B, i, src2, (op.flags & F_Z2ONE) != 0);
+            }
+        }
+        B.src[(size_t)(2 * t + 1) * B.n + i] = (uint16_t)(src2 | (digit != 0 ? SRC_SEL_BIT : 0));
+        const JacL p2 = jacl_from(p2w);
+        if ((op.flags & F_Z1ONE) && z2one)
+            res = jac_add29<true, true>(p1, p2);
+        else if (z2one)
+            res = jac_add29<false, true>(p1, p2);
+        else if (op.flags & F_Z1ONE)
+            res = jac_add29<true, false>(p1, p2);
+        else
+            res = jac_add29<false, false>(p1, p2);
+        if (op.kind == OP_CADD) B.dyn[(size_t)op.cadd_idx * B.n + i] = digit != 0 ? (uint16_t)t : src1;
+    }
+    if (!(op.flags & F_NO_AFFINE)) {
+        B.PX[o] = f29_canon(res.p.X);
+        B.PY[o] = f29_canon(res.p.Y);
+    }
+    const U256 zc = f29_canon(res.p.Z);
+    B.PZ[o] = zc;
+    B.PW[o] = f29_canon(res.W);
+    B.PREF[o] = f29_canon(st.acc);
+    const bool z_zero = u256_is_zero(zc);
+    if (z_zero) err_or(&B.err[i], ERR_INVERSE_OF_ZERO);   // reference: inverse() of zero panics (gadgets/nonnative.rs:863)
+    st.acc = f29_mul(st.acc, f29_select(z_zero, f29_small(1), res.p.Z));
+    st.p1 = p1;
+    st.p1_id = (op.flags & F_Z1ONE) ? (uint16_t)0xFFFF : src1;   // an affine operand has no Z to carry
+    st.out = res.p;
+    st.out_id = (uint16_t)t;
+}
+P2E_HD ChainState29 chain_state29_init(const U256& acc) {
+    ChainState29 st;
+    st.out_id = st.p1_id = 0xFFFF;
+    st.out.X = st.out.Y = st.out.Z = st.p1.X = st.p1.Y = st.p1.Z = f29_small(0);
+    st.acc = f29_from_u256(acc);
+    return st;
+}
 // Product of the Z3 values (zeros replaced by one) of ops [lo, hi) given the prefix array: prefix of the
 // last op times its own Z3.
 template <class CV = Secp256k1>
@@ -398,6 +478,11 @@ P2E_HD U256 range_product(const Buffers& B, size_t i, int last) {
 template <class CV = Secp256k1, bool GENERIC = false>
 P2E_HD void body_chain_range(const Program& G, const Buffers& B, size_t i, int lo, int hi, bool table_affine,
                              bool continue_prefix, const Aff* lds_fb = nullptr, u32 lds_w0 = 0) {
+    if (LazyLimbs<CV>::available) {
+        ChainState29 st = chain_state29_init(continue_prefix ? range_product<CV>(B, i, lo - 1) : u256_small(1));
+        for (int t = lo; t < hi; t++) body_chain_op29<GENERIC>(G, B, i, t, table_affine, st, lds_fb, lds_w0);
+        return;
+    }
     ChainState st;
     st.out_id = st.p1_id = 0xFFFF;
     st.out.X = st.out.Y = st.out.Z = st.p1.X = st.p1.Y = st.p1.Z = u256_zero();
@@ -411,11 +496,8 @@ P2E_HD void body_chain_range(const Program& G, const Buffers& B, size_t i, int l
 // row).  Walking the rows with different lanes shortens the latency-bound start of every call from 23 dependent
 // ops to 6.  The prefix products of the piece's inversion batch are then left to phase B (have_prefix = false).
 P2E_HD void body_chain_rows(const Program& G, const Buffers& B, size_t i, int lo, int rows, int row, int count) {
-    ChainState st;
-    st.out_id = st.p1_id = 0xFFFF;
-    st.out.X = st.out.Y = st.out.Z = st.p1.X = st.p1.Y = st.p1.Z = u256_zero();
-    st.acc = u256_small(1);
-    for (int j = 0; j < count; j++) body_chain_op(G, B, i, lo + row + j * rows, false, st);
+    ChainState29 st = chain_state29_init(u256_small(1));
+    for (int j = 0; j < count; j++) body_chain_op29(G, B, i, lo + row + j * rows, false, st);
 }
 
 // The connect r == x of gadgets/ecdsa.rs:48-52 on the final add's JACOBIAN result (p2e_ecdsa_verify_batch: verdict
@@ -432,6 +514,66 @@ P2E_HD void body_verify_check(const Program& G, const Buffers& B, size_t i) {
     body_verify_check<Secp256k1>(G, B, i, G.chain_end[2] - 1);
 }
 
+// body_batch_inv (below) for secp256k1 on lazy limbs (fe29.hpp): the same
+// products in the same order -- v^-1 = W * (inv * prefix), inv *= Z, and for the ops that keep an affine form
+// X * zi^2, Y * zi^3 -- with three differences that only change the time: the multiplications are fe29's, a value is
+// made canonical only where it is stored, and the inputs of op t - 1 are requested before op t is computed (the loop
+// as written below exposes one memory round trip per op to a wave that has nothing else to do).
+// The loads are unconditional (an op without an affine form reads its Z twice more instead of X and Y: a load inside a
+// divergent branch drags its wait to the join).
+P2E_HD void body_batch_inv29(const Buffers& B, size_t i, int t0, int t1, bool have_prefix, bool uniform_t) {
+    U256 accw;
+    if (have_prefix) {
+        accw = range_product<Secp256k1>(B, i, t1 - 1);
+    } else {
+        F29 acc = f29_small(1);
+        for (int t = t0; t < t1; t++) {
+            const size_t o = (size_t)t * B.n + i;
+            U256 z = B.PZ[o];
+            if (u256_is_zero(z)) z = u256_small(1);   // flagged by phase A
+            B.PREF[o] = f29_canon(acc);
+            acc = f29_mul(acc, f29_from_u256(z));
+        }
+        accw = f29_canon(acc);
+    }
+    F29 inv = f29_from_u256(fe_inv<ModP>(accw));
+    struct In {
+        U256 z, pref, w, x, y;
+        uint8_t flags;
+    };
+    auto flags_of = [&](int t) { return uniform_t ? load_op(B.ops, t < t0 ? t0 : t).flags : B.ops[t < t0 ? t0 : t].flags; };
+    auto fetch = [&](int t, uint8_t fl) {
+        In r;
+        const size_t o = (size_t)(t < t0 ? t0 : t) * B.n + i;
+        const bool aff = !(fl & F_NO_AFFINE);
+        r.z = B.PZ[o];
+        r.pref = B.PREF[o];
+        r.w = B.PW[o];
+        r.x = *(aff ? &B.PX[o] : &B.PZ[o]);
+        r.y = *(aff ? &B.PY[o] : &B.PZ[o]);
+        r.flags = fl;
+        return r;
+    };
+    uint8_t f_nxt = flags_of(t1 - 2);
+    In cur = fetch(t1 - 1, flags_of(t1 - 1));
+    for (int t = t1 - 1; t >= t0; t--) {
+        const uint8_t f_n2 = flags_of(t - 2);
+        const In nxt = fetch(t - 1, f_nxt);
+        const size_t o = (size_t)t * B.n + i;
+        const U256 z = u256_select(u256_is_zero(cur.z), u256_small(1), cur.z);
+        const F29 zi = f29_mul(inv, f29_from_u256(cur.pref));
+        inv = f29_mul(inv, f29_from_u256(z));
+        B.PW[o] = f29_canon(f29_mul(f29_from_u256(cur.w), zi));   // v^-1 of op t
+        if (!(cur.flags & F_NO_AFFINE)) {
+            const F29 zi2 = f29_sqr(zi);
+            const F29 zi3 = f29_mul(zi2, zi);
+            B.AX[o] = f29_canon(f29_mul(f29_from_u256(cur.x), zi2));
+            B.AY[o] = f29_canon(f29_mul(f29_from_u256(cur.y), zi3));
+        }
+        cur = nxt;
+        f_nxt = f_n2;
+    }
+}
 // ---- phase B: Montgomery batch inversion of Z over ops [t0, t1) of one signature ------------------------
 // Reads the Jacobian results (left intact: later pieces of the chain still consume them), writes the
 // affine points to AX/AY and v^-1 over W.  have_prefix: [t0, t1) is exactly one inversion batch of phase A,
@@ -442,6 +584,10 @@ template <class CV = Secp256k1>
 P2E_HD void body_batch_inv(const Program& G, const Buffers& B, size_t i, int t0, int t1, bool have_prefix, bool uniform_t = true) {
     (void)G;
     typedef typename CV::Fp F;
+    if (LazyLimbs<CV>::available) {
+        body_batch_inv29(B, i, t0, t1, have_prefix, uniform_t);
+        return;
+    }
     U256 acc;
     if (have_prefix) {
         acc = range_product<CV>(B, i, t1 - 1);

@@ -599,85 +599,13 @@ P2E_HD void body_chain_range_quad(const Program& G, const Buffers& B, size_t i, 
 // Phase B of ops [t0, t1) with the backward pass cut into S sub-ranges; this lane walks sub-range q.  With phase A's
 // cumulative prefix products (have_prefix) a sub-range starts from the inverse of the product THROUGH its last op,
 // which is one inversion of its own: S inversions run side by side instead of one followed by a t1 - t0 long walk.
-// body_batch_inv (pipeline.hpp) for secp256k1 on lazy limbs (fe29.hpp), lanes of a wave walking different ops: the same
-// products in the same order -- v^-1 = W * (inv * prefix), inv *= Z, and for the ops that keep an affine form
-// X * zi^2, Y * zi^3 -- with three differences that only change the time: the multiplications are fe29's, a value is
-// made canonical only where it is stored, and the inputs of op t - 1 are requested before op t is computed (the loop
-// as written in pipeline.hpp exposes one memory round trip per op to a wave that has nothing else to do).
-// The loads are unconditional (an op without an affine form reads its Z twice more instead of X and Y: a load inside a
-// divergent branch drags its wait to the join).
-P2E_HD void body_batch_inv29(const Buffers& B, size_t i, int t0, int t1, bool have_prefix) {
-    U256 accw;
-    if (have_prefix) {
-        accw = range_product<Secp256k1>(B, i, t1 - 1);
-    } else {
-        F29 acc = f29_small(1);
-        for (int t = t0; t < t1; t++) {
-            const size_t o = (size_t)t * B.n + i;
-            U256 z = B.PZ[o];
-            if (u256_is_zero(z)) z = u256_small(1);   // flagged by phase A
-            B.PREF[o] = f29_canon(acc);
-            acc = f29_mul(acc, f29_from_u256(z));
-        }
-        accw = f29_canon(acc);
-    }
-    F29 inv = f29_from_u256(fe_inv<ModP>(accw));
-    struct In {
-        U256 z, pref, w, x, y;
-        uint8_t flags;
-    };
-    auto flags_of = [&](int t) { return B.ops[t < t0 ? t0 : t].flags; };
-    auto fetch = [&](int t, uint8_t fl) {
-        In r;
-        const size_t o = (size_t)(t < t0 ? t0 : t) * B.n + i;
-        const bool aff = !(fl & F_NO_AFFINE);
-        r.z = B.PZ[o];
-        r.pref = B.PREF[o];
-        r.w = B.PW[o];
-        r.x = *(aff ? &B.PX[o] : &B.PZ[o]);
-        r.y = *(aff ? &B.PY[o] : &B.PZ[o]);
-        r.flags = fl;
-        return r;
-    };
-    uint8_t f_nxt = flags_of(t1 - 2);
-    In cur = fetch(t1 - 1, flags_of(t1 - 1));
-    for (int t = t1 - 1; t >= t0; t--) {
-        const uint8_t f_n2 = flags_of(t - 2);
-        const In nxt = fetch(t - 1, f_nxt);
-        const size_t o = (size_t)t * B.n + i;
-        const U256 z = u256_select(u256_is_zero(cur.z), u256_small(1), cur.z);
-        const F29 zi = f29_mul(inv, f29_from_u256(cur.pref));
-        inv = f29_mul(inv, f29_from_u256(z));
-        B.PW[o] = f29_canon(f29_mul(f29_from_u256(cur.w), zi));   // v^-1 of op t
-        if (!(cur.flags & F_NO_AFFINE)) {
-            const F29 zi2 = f29_sqr(zi);
-            const F29 zi3 = f29_mul(zi2, zi);
-            B.AX[o] = f29_canon(f29_mul(f29_from_u256(cur.x), zi2));
-            B.AY[o] = f29_canon(f29_mul(f29_from_u256(cur.y), zi3));
-        }
-        cur = nxt;
-        f_nxt = f_n2;
-    }
-}
-template <class CV>
-struct LazyLimbs {
-    static constexpr bool available = false;
-};
-template <>
-struct LazyLimbs<Secp256k1> {
-    static constexpr bool available = true;
-};
-
 template <class CV = Secp256k1>
 P2E_HD void body_batch_inv_split(const Program& G, const Buffers& B, size_t i, int t0, int t1, bool have_prefix, int q, int S) {
     const int len = t1 - t0;
     const int a = t0 + (int)(((long long)len * q) / S), b = t0 + (int)(((long long)len * (q + 1)) / S);
     if (a >= b) return;
     // (have_prefix: PREF[t] is the product from the piece's first op, so [a, b) needs no forward pass of its own)
-    if (LazyLimbs<CV>::available)
-        body_batch_inv29(B, i, a, b, have_prefix);
-    else
-        body_batch_inv<CV>(G, B, i, a, b, have_prefix, false);   // lanes of one wave walk different ops
+    body_batch_inv<CV>(G, B, i, a, b, have_prefix, false);   // lanes of one wave walk different ops
 }
 
 // ---- curve programs (curves.hpp): any op list of either curve, four lanes per signature ------------------------------

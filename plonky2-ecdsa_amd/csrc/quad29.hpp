@@ -15,28 +15,9 @@
 // inverse() panics on it: gadgets/nonnative.rs:863).  Y3 only exists after the last level; the few ops that need it
 // convert it there.
 #pragma once
-#include "fe29.hpp"
 #include "pipeline.hpp"
 
 namespace p2e {
-
-struct JacL {
-    F29 X, Y, Z;   // tight limbs
-};
-P2E_HD JacL jacl_from(const Jac& p) {
-    JacL r;
-    r.X = f29_from_u256(p.X);
-    r.Y = f29_from_u256(p.Y);
-    r.Z = f29_from_u256(p.Z);
-    return r;
-}
-P2E_HD Jac jacl_canon(const JacL& p) {
-    Jac r;
-    r.X = f29_canon(p.X);
-    r.Y = f29_canon(p.Y);
-    r.Z = f29_canon(p.Z);
-    return r;
-}
 
 // quad_level (quad.hpp) on lazy limbs.  Every pair must satisfy f29_mul's bound on its own: the emulation build
 // multiplies all four and checks each.
