@@ -58,58 +58,58 @@ P2E_HD JacWL jac_add29(const JacL& p1, const JacL& p2) {
         u1 = p1.X;
         s1 = p1.Y;
     } else {
-        const F29 zz = f29_sqr(p2.Z);
-        z2c = f29_mul(zz, p2.Z);
-        u1 = f29_mul(p1.X, zz);
-        s1 = f29_mul(p1.Y, z2c);
+        const F29 zz = f29_sqr_call(p2.Z);
+        z2c = f29_mul_call(zz, p2.Z);
+        u1 = f29_mul_call(p1.X, zz);
+        s1 = f29_mul_call(p1.Y, z2c);
     }
     if (Z1ONE) {
         u2 = p2.X;
         s2 = p2.Y;
     } else {
-        const F29 zz = f29_sqr(p1.Z);
-        z1c = f29_mul(zz, p1.Z);
-        u2 = f29_mul(p2.X, zz);
-        s2 = f29_mul(p2.Y, z1c);
+        const F29 zz = f29_sqr_call(p1.Z);
+        z1c = f29_mul_call(zz, p1.Z);
+        u2 = f29_mul_call(p2.X, zz);
+        s2 = f29_mul_call(p2.Y, z1c);
     }
     const F29 h = f29_norm(f29_sub<1>(u2, u1));
     const F29 r = f29_norm(f29_sub<1>(s2, s1));
-    const F29 h2 = f29_sqr(h);
-    const F29 h3 = f29_mul(h2, h);
-    const F29 v = f29_mul(u1, h2);
+    const F29 h2 = f29_sqr_call(h);
+    const F29 h3 = f29_mul_call(h2, h);
+    const F29 v = f29_mul_call(u1, h2);
     JacWL o;
-    o.p.X = f29_norm(f29_sub<2>(f29_sub<1>(f29_sqr(r), h3), f29_times<2>(v)));
-    o.p.Y = f29_norm(f29_sub<1>(f29_mul(r, f29_sub<1>(v, o.p.X)), f29_mul(s1, h3)));
+    o.p.X = f29_norm(f29_sub<2>(f29_sub<1>(f29_sqr_call(r), h3), f29_times<2>(v)));
+    o.p.Y = f29_norm(f29_sub<1>(f29_mul_call(r, f29_sub<1>(v, o.p.X)), f29_mul_call(s1, h3)));
     if (Z1ONE && Z2ONE) {
         o.p.Z = h;
         o.W = f29_small(1);
     } else if (Z1ONE) {
-        o.p.Z = f29_mul(p2.Z, h);
+        o.p.Z = f29_mul_call(p2.Z, h);
         o.W = z2c;
     } else if (Z2ONE) {
-        o.p.Z = f29_mul(p1.Z, h);
+        o.p.Z = f29_mul_call(p1.Z, h);
         o.W = z1c;
     } else {
-        o.p.Z = f29_mul(f29_mul(p1.Z, p2.Z), h);
-        o.W = f29_mul(z1c, z2c);
+        o.p.Z = f29_mul_call(f29_mul_call(p1.Z, p2.Z), h);
+        o.W = f29_mul_call(z1c, z2c);
     }
     return o;
 }
 // jac_dbl_cv<Secp256k1> (ec.hpp; a = 0)
 P2E_HD JacWL jac_dbl29(const JacL& p) {
-    const F29 a = f29_sqr(p.X);
-    const F29 b = f29_sqr(p.Y);
-    const F29 c = f29_sqr(b);
-    const F29 t = f29_norm(f29_sub<1>(f29_sub<1>(f29_sqr(f29_add(p.X, b)), a), c));
+    const F29 a = f29_sqr_call(p.X);
+    const F29 b = f29_sqr_call(p.Y);
+    const F29 c = f29_sqr_call(b);
+    const F29 t = f29_norm(f29_sub<1>(f29_sub<1>(f29_sqr_call(f29_add(p.X, b)), a), c));
     const F29 d = f29_times<2>(t);
     const F29 e = f29_norm(f29_times<3>(a));
-    const F29 f = f29_sqr(e);
+    const F29 f = f29_sqr_call(e);
     JacWL o;
     o.p.X = f29_norm(f29_sub<4>(f, f29_times<2>(d)));
     const F29 c8 = f29_times<2>(f29_norm(f29_times<4>(c)));
-    o.p.Y = f29_norm(f29_sub<2>(f29_mul(e, f29_sub<1>(d, o.p.X)), c8));
-    o.p.Z = f29_norm(f29_times<2>(f29_mul(p.Y, p.Z)));
-    o.W = f29_sqr(f29_sqr(p.Z));
+    o.p.Y = f29_norm(f29_sub<2>(f29_mul_call(e, f29_sub<1>(d, o.p.X)), c8));
+    o.p.Z = f29_norm(f29_times<2>(f29_mul_call(p.Y, p.Z)));
+    o.W = f29_sqr_call(f29_sqr_call(p.Z));
     return o;
 }
 

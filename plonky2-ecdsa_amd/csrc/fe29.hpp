@@ -272,6 +272,32 @@ P2E_HD F29 f29_sqr(const F29& a) {
     return r;
 }
 
+// Out-of-line forms for the kernels whose walkers would otherwise inline a hundred multiplications (lane per signature:
+// every variant of the addition and the doubling, ~80 KB of code against a 64 KB instruction cache shared by two CUs
+// and by the expansion kernels running beside the chains).  Arguments and result travel in VGPRs, as for fe_mul_call.
+// (eighteen scalars: clang passes at most 16 registers' worth of aggregates per call and would hand the second operand
+// over in scratch memory)
+template <int UNUSED = 0>
+P2E_HD_NOINLINE F29 f29_mul_call_regs(u32 a0, u32 a1, u32 a2, u32 a3, u32 a4, u32 a5, u32 a6, u32 a7, u32 a8, u32 b0, u32 b1, u32 b2,
+                                      u32 b3, u32 b4, u32 b5, u32 b6, u32 b7, u32 b8) {
+    F29 a, b;
+    a.l[0] = a0, a.l[1] = a1, a.l[2] = a2, a.l[3] = a3, a.l[4] = a4, a.l[5] = a5, a.l[6] = a6, a.l[7] = a7, a.l[8] = a8;
+    b.l[0] = b0, b.l[1] = b1, b.l[2] = b2, b.l[3] = b3, b.l[4] = b4, b.l[5] = b5, b.l[6] = b6, b.l[7] = b7, b.l[8] = b8;
+    return f29_mul(a, b);
+}
+P2E_HD F29 f29_mul_call(const F29& a, const F29& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return f29_mul_call_regs(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], b.l[0], b.l[1], b.l[2], b.l[3],
+                             b.l[4], b.l[5], b.l[6], b.l[7], b.l[8]);
+#else
+    return f29_mul(a, b);   // (the emulation build keeps the bounds that ride beside the limbs)
+#endif
+}
+template <int UNUSED = 0>
+P2E_HD_NOINLINE F29 f29_sqr_call(F29 a) {
+    return f29_sqr(a);
+}
+
 // The canonical 8-word form (what fe.hpp computes with, what scratch memory and the witness hold): fold the bits above
 // 2^256 through 2^256 = 2^32 + 977, one strict carry pass, repack to 32-bit words, one conditional subtraction of p.
 // Any limbs below 2^31 in.
@@ -309,6 +335,10 @@ P2E_HD U256 f29_canon(const F29& a) {
     P2E_UNROLL
     for (int k = 2; k < 8; k++) y.w[k] = addc32(x.w[k], 0u, c);
     return u256_select((c | over) != 0, y, x);
+}
+template <int UNUSED = 0>
+P2E_HD_NOINLINE U256 f29_canon_call(F29 a) {
+    return f29_canon(a);
 }
 P2E_HD bool f29_is_zero(const F29& a) { return u256_is_zero(f29_canon(a)); }
 

@@ -442,16 +442,16 @@ P2E_HD void body_chain_op29(const Program& G, const Buffers& B, size_t i, int t,
         if (op.kind == OP_CADD) B.dyn[(size_t)op.cadd_idx * B.n + i] = digit != 0 ? (uint16_t)t : src1;
     }
     if (!(op.flags & F_NO_AFFINE)) {
-        B.PX[o] = f29_canon(res.p.X);
-        B.PY[o] = f29_canon(res.p.Y);
+        B.PX[o] = f29_canon_call(res.p.X);
+        B.PY[o] = f29_canon_call(res.p.Y);
     }
-    const U256 zc = f29_canon(res.p.Z);
+    const U256 zc = f29_canon_call(res.p.Z);
     B.PZ[o] = zc;
-    B.PW[o] = f29_canon(res.W);
-    B.PREF[o] = f29_canon(st.acc);
+    B.PW[o] = f29_canon_call(res.W);
+    B.PREF[o] = f29_canon_call(st.acc);
     const bool z_zero = u256_is_zero(zc);
     if (z_zero) err_or(&B.err[i], ERR_INVERSE_OF_ZERO);   // reference: inverse() of zero panics (gadgets/nonnative.rs:863)
-    st.acc = f29_mul(st.acc, f29_select(z_zero, f29_small(1), res.p.Z));
+    st.acc = f29_mul_call(st.acc, f29_select(z_zero, f29_small(1), res.p.Z));
     st.p1 = p1;
     st.p1_id = (op.flags & F_Z1ONE) ? (uint16_t)0xFFFF : src1;   // an affine operand has no Z to carry
     st.out = res.p;
@@ -531,10 +531,10 @@ P2E_HD void body_batch_inv29(const Buffers& B, size_t i, int t0, int t1, bool ha
             const size_t o = (size_t)t * B.n + i;
             U256 z = B.PZ[o];
             if (u256_is_zero(z)) z = u256_small(1);   // flagged by phase A
-            B.PREF[o] = f29_canon(acc);
-            acc = f29_mul(acc, f29_from_u256(z));
+            B.PREF[o] = f29_canon_call(acc);
+            acc = f29_mul_call(acc, f29_from_u256(z));
         }
-        accw = f29_canon(acc);
+        accw = f29_canon_call(acc);
     }
     F29 inv = f29_from_u256(fe_inv<ModP>(accw));
     struct In {
@@ -561,14 +561,14 @@ P2E_HD void body_batch_inv29(const Buffers& B, size_t i, int t0, int t1, bool ha
         const In nxt = fetch(t - 1, f_nxt);
         const size_t o = (size_t)t * B.n + i;
         const U256 z = u256_select(u256_is_zero(cur.z), u256_small(1), cur.z);
-        const F29 zi = f29_mul(inv, f29_from_u256(cur.pref));
-        inv = f29_mul(inv, f29_from_u256(z));
-        B.PW[o] = f29_canon(f29_mul(f29_from_u256(cur.w), zi));   // v^-1 of op t
+        const F29 zi = f29_mul_call(inv, f29_from_u256(cur.pref));
+        inv = f29_mul_call(inv, f29_from_u256(z));
+        B.PW[o] = f29_canon_call(f29_mul_call(f29_from_u256(cur.w), zi));   // v^-1 of op t
         if (!(cur.flags & F_NO_AFFINE)) {
-            const F29 zi2 = f29_sqr(zi);
-            const F29 zi3 = f29_mul(zi2, zi);
-            B.AX[o] = f29_canon(f29_mul(f29_from_u256(cur.x), zi2));
-            B.AY[o] = f29_canon(f29_mul(f29_from_u256(cur.y), zi3));
+            const F29 zi2 = f29_sqr_call(zi);
+            const F29 zi3 = f29_mul_call(zi2, zi);
+            B.AX[o] = f29_canon_call(f29_mul_call(f29_from_u256(cur.x), zi2));
+            B.AY[o] = f29_canon_call(f29_mul_call(f29_from_u256(cur.y), zi3));
         }
         cur = nxt;
         f_nxt = f_n2;
