@@ -918,6 +918,152 @@ P2E_HD bool fe_inv_bingcd(const U256& y, U256& result) {
     return ok;
 }
 
+// ------------------------------------------------------------------------------------------------
+// modular inversion by "safegcd" (D. J. Bernstein, B.-Y. Yang, "Fast constant-time gcd computation and modular
+// inversion", 2019) in the 32-bit formulation published with libsecp256k1 (doc/safegcd_implementation.md: signed 30-bit
+// limbs, 30 division steps at a time on the low limbs alone, then ONE exact update of the full-width f, g and d, e by the
+// 2 x 2 transition matrix).  20 x 30 = 600 steps cover any 256-bit modulus (590 needed).  Every step is mask
+// arithmetic on 32-bit values -- no 64-bit compares, no carry chains through VCC -- which is what makes it 2.2 x faster
+// than fe_inv_bingcd above for a lone wave (35 against 77 us, tools/ubench/fe29_latency.hip): the inversion is on the
+// critical path of every call twice over (s^-1 in the scalar phase, the window table's inversion batch).
+// Returns false if gcd(y, m) != 1, i.e. for y = 0 (the caller's Fermat ladder then yields the reference's 0).
+// ------------------------------------------------------------------------------------------------
+template <class MOD>
+P2E_HD bool fe_inv_safegcd(const U256& y, U256& result) {
+    typedef int32_t i32;
+    const i32 M30 = (i32)((1u << 30) - 1u);
+    i32 m[9], d[9], e[9], f[9], g[9];
+    {   // 8 x 32-bit words -> 9 x 30-bit limbs
+        u32 mw[9], yw[9];
+        P2E_UNROLL
+        for (int i = 0; i < 8; i++) {
+            mw[i] = MOD::m(i);
+            yw[i] = y.w[i];
+        }
+        mw[8] = yw[8] = 0;
+        P2E_UNROLL
+        for (int i = 0; i < 9; i++) {
+            const int bit = 30 * i, wi = bit >> 5, sh = bit & 31;
+            u32 lm = mw[wi] >> sh, ly = yw[wi] >> sh;
+            if (sh > 2 && wi + 1 < 9) {
+                lm |= mw[wi + 1] << (32 - sh);
+                ly |= yw[wi + 1] << (32 - sh);
+            }
+            m[i] = (i32)(lm & (u32)M30);
+            g[i] = (i32)(ly & (u32)M30);
+            f[i] = m[i];
+            d[i] = 0;
+            e[i] = i == 0 ? 1 : 0;
+        }
+    }
+    u32 minv = (u32)m[0];   // m^-1 mod 2^30 (Newton: 5 doublings of the 3 bits every odd number is its own inverse to)
+    P2E_UNROLL
+    for (int k = 0; k < 5; k++) minv *= 2u - (u32)m[0] * minv;
+    minv &= (u32)M30;
+    i32 zeta = -1;   // -(delta + 1/2), delta = 1/2
+    for (int it = 0; it < 20; it++) {
+        // ---- 30 division steps on the low limbs: t = [u v; q r] with t [f; g] = 2^30 [f'; g']
+        u32 u = 1, v = 0, q = 0, r = 1, ff = (u32)f[0], gg = (u32)g[0];
+        for (int i = 0; i < 30; i++) {
+            u32 c1 = (u32)(zeta >> 31);          // all ones if zeta < 0
+            const u32 c2 = 0u - (gg & 1u);       // all ones if g is odd
+            const u32 x = (ff ^ c1) - c1, yy = (u ^ c1) - c1, z = (v ^ c1) - c1;   // f, u, v negated if zeta < 0
+            gg += x & c2;
+            q += yy & c2;
+            r += z & c2;
+            c1 &= c2;
+            zeta = (i32)(((u32)zeta ^ c1) - 1u);
+            ff += gg & c1;
+            u += q & c1;
+            v += r & c1;
+            gg >>= 1;
+            u <<= 1;
+            v <<= 1;
+        }
+        const i32 tu = (i32)u, tv = (i32)v, tq = (i32)q, tr = (i32)r;
+        // ---- (d, e) <- t (d, e) / 2^30 mod m, kept in (-2 m, m)
+        {
+            const i32 sd = d[8] >> 31, se = e[8] >> 31;
+            i32 md = (tu & sd) + (tv & se), me = (tq & sd) + (tr & se);
+            i64 cd = (i64)tu * d[0] + (i64)tv * e[0], ce = (i64)tq * d[0] + (i64)tr * e[0];
+            md -= (i32)((minv * (u32)cd + (u32)md) & (u32)M30);
+            me -= (i32)((minv * (u32)ce + (u32)me) & (u32)M30);
+            cd += (i64)m[0] * md;
+            ce += (i64)m[0] * me;
+            cd >>= 30;
+            ce >>= 30;
+            P2E_UNROLL
+            for (int i = 1; i < 9; i++) {
+                cd += (i64)tu * d[i] + (i64)tv * e[i];
+                ce += (i64)tq * d[i] + (i64)tr * e[i];
+                cd += (i64)m[i] * md;
+                ce += (i64)m[i] * me;
+                d[i - 1] = (i32)cd & M30;
+                e[i - 1] = (i32)ce & M30;
+                cd >>= 30;
+                ce >>= 30;
+            }
+            d[8] = (i32)cd;
+            e[8] = (i32)ce;
+        }
+        // ---- (f, g) <- t (f, g) / 2^30 (exact)
+        {
+            i64 cf = (i64)tu * f[0] + (i64)tv * g[0], cg = (i64)tq * f[0] + (i64)tr * g[0];
+            cf >>= 30;
+            cg >>= 30;
+            P2E_UNROLL
+            for (int i = 1; i < 9; i++) {
+                cf += (i64)tu * f[i] + (i64)tv * g[i];
+                cg += (i64)tq * f[i] + (i64)tr * g[i];
+                f[i - 1] = (i32)cf & M30;
+                g[i - 1] = (i32)cg & M30;
+                cf >>= 30;
+                cg >>= 30;
+            }
+            f[8] = (i32)cf;
+            g[8] = (i32)cg;
+        }
+    }
+    // g = 0 and f = +-1 unless gcd(y, m) != 1
+    i32 gz = 0, f_one = f[0] ^ 1, f_minus = (f[0] ^ M30) | (f[8] ^ -1);
+    P2E_UNROLL
+    for (int i = 0; i < 9; i++) gz |= g[i];
+    P2E_UNROLL
+    for (int i = 1; i < 9; i++) f_one |= f[i];
+    P2E_UNROLL
+    for (int i = 1; i < 8; i++) f_minus |= f[i] ^ M30;
+    const bool ok = gz == 0 && (f_one == 0 || f_minus == 0);
+    // y^-1 = sign(f) d, brought into [0, m)
+    {
+        i32 add = d[8] >> 31;
+        const i32 neg = f[8] >> 31;
+        P2E_UNROLL
+        for (int i = 0; i < 9; i++) d[i] = ((d[i] + (m[i] & add)) ^ neg) - neg;
+        P2E_UNROLL
+        for (int i = 0; i < 8; i++) {
+            d[i + 1] += d[i] >> 30;
+            d[i] &= M30;
+        }
+        add = d[8] >> 31;
+        P2E_UNROLL
+        for (int i = 0; i < 9; i++) d[i] += m[i] & add;
+        P2E_UNROLL
+        for (int i = 0; i < 8; i++) {
+            d[i + 1] += d[i] >> 30;
+            d[i] &= M30;
+        }
+    }
+    P2E_UNROLL
+    for (int j = 0; j < 8; j++) {   // 9 x 30-bit limbs -> 8 x 32-bit words
+        const int bit = 32 * j, li = bit / 30, sh = bit - 30 * li;
+        u32 w = (u32)d[li] >> sh;
+        w |= (u32)d[li + 1] << (30 - sh);
+        if (60 - sh < 32 && li + 2 < 9) w |= (u32)d[li + 2] << (60 - sh);
+        result.w[j] = w;
+    }
+    return ok;
+}
+
 // a^(m-2) mod m by plain square-and-multiply (the low word of every modulus here is >= 2: no borrow).  Only the
 // fallback of fe_inv for the moduli without a dedicated ladder, i.e. reached by zero inputs.
 template <class MOD>
@@ -934,19 +1080,19 @@ P2E_HD U256 fe_inv_fermat(const U256& a) {
 template <class MOD>
 P2E_HD U256 fe_inv(const U256& a) {
     U256 r;
-    if (fe_inv_bingcd<MOD>(a, r)) return r;
+    if (fe_inv_safegcd<MOD>(a, r)) return r;
     return fe_inv_fermat<MOD>(a);
 }
 template <>
 P2E_HD U256 fe_inv<ModP>(const U256& a) {
     U256 r;
-    if (fe_inv_bingcd<ModP>(a, r)) return r;
-    return fe_inv_p(a);   // a == 0 (result 0 either way) or the (never observed) round-bound miss
+    if (fe_inv_safegcd<ModP>(a, r)) return r;
+    return fe_inv_p(a);   // a == 0: the reference's inverse of zero is a^(p-2) = 0
 }
 template <>
 P2E_HD U256 fe_inv<ModN>(const U256& a) {
     U256 r;
-    if (fe_inv_bingcd<ModN>(a, r)) return r;
+    if (fe_inv_safegcd<ModN>(a, r)) return r;
     return fe_inv_n(a);
 }
 

@@ -595,7 +595,7 @@ struct p2e_ctx {
     // fixed-base batch (67 ops that all keep their affine form: the longest) queued behind it used to hold up the second
     // loop piece's batch in turn.  0: the round-2 order.
     int quad_b_first_on_fixed = 1;
-    unsigned expand_lds_small = 160000;
+    unsigned expand_lds_small = 54000;   // (160 000 -- one expansion workgroup per CU -- while the chains were the bottleneck; with lazy-limb chains 54 000 is 3-4 % faster at 2^13, profiles/r03_quad_plan_lazy_limbs_sweeps.txt)
     unsigned expand_lds = 0;   // the same knob for the large-batch plan
     Aff* d_cpts = nullptr;
     Aff* d_fbtab = nullptr;

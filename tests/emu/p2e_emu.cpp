@@ -241,6 +241,17 @@ extern "C" long emu_f29_selftest(unsigned long long seed, size_t n) {
     return fails;
 }
 
+// the same stress loop for fe_inv_safegcd (csrc/fe.hpp), over all four moduli of the crate (field: 0 p, 1 n of secp256k1,
+// 2 p, 3 n of P-256): x * inv(x) == 1, the result is canonical and equal to fe_inv_bingcd's; zero is reported as not invertible
+template <class MOD>
+static long safegcd_one(const U256& raw) {
+    const U256 x = fe_canon<MOD>(fe_canon<MOD>(raw));
+    U256 r, r2;
+    const bool ok = fe_inv_safegcd<MOD>(x, r);
+    if (u256_is_zero(x)) return ok ? 1 : 0;
+    const bool ok2 = fe_inv_bingcd<MOD>(x, r2);
+    return (ok && ok2 && u256_eq(r, r2) && !geq_mod<MOD>(r.w) && u256_eq(fe_mul<MOD>(x, r), u256_small(1))) ? 0 : 1;
+}
 extern "C" {
 // raw access to the binary-GCD inversion (csrc/fe.hpp) for the stress test: ok[i] = round bound held
 long emu_bingcd(int field, const uint8_t* x32, uint8_t* inv32, uint8_t* ok, size_t n) {
@@ -281,6 +292,34 @@ long emu_bingcd_selfcheck(int field, unsigned long long seed, size_t n) {
         bool ok = field ? fe_inv_bingcd<ModN>(x, r) : fe_inv_bingcd<ModP>(x, r);
         U256 one = field ? fe_mul<ModN>(x, r) : fe_mul<ModP>(x, r);
         if (!ok || !u256_eq(one, u256_small(1))) fails++;
+    }
+    return fails;
+}
+long emu_safegcd_selfcheck(int field, unsigned long long seed, size_t n) {
+    long fails = 0;
+#pragma omp parallel for reduction(+ : fails)
+    for (long long i = 0; i < (long long)n; i++) {
+        host::SplitMix64 rng{seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1))};
+        U256 x;
+        unsigned long long sel = rng.next();
+        for (int k = 0; k < 4; k++) {
+            unsigned long long w = rng.next();
+            unsigned pat = (unsigned)(sel >> (8 * k)) & 7;
+            if (pat == 0) w = 0;
+            if (pat == 1) w = ~0ull;
+            if (pat == 2) w &= 0xFFFFFFFFull;
+            x.w[2 * k] = (u32)w;
+            x.w[2 * k + 1] = (u32)(w >> 32);
+        }
+        int bits = 1 + (int)((sel >> 40) % 256);
+        if ((sel >> 50) & 1)
+            for (int b = bits; b < 256; b++) x.w[b >> 5] &= ~(1u << (b & 31));
+        if (((sel >> 52) & 63) == 0) {   // m - small
+            x = u256_zero();
+            x.w[0] = (u32)(sel >> 58) + 1u;
+            x = field == 0 ? fe_neg<ModP>(x) : field == 1 ? fe_neg<ModN>(x) : field == 2 ? fe_neg<ModP256>(x) : fe_neg<ModN256>(x);
+        }
+        fails += field == 0 ? safegcd_one<ModP>(x) : field == 1 ? safegcd_one<ModN>(x) : field == 2 ? safegcd_one<ModP256>(x) : safegcd_one<ModN256>(x);
     }
     return fails;
 }

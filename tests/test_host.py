@@ -211,6 +211,17 @@ def test_batch_inversion_chunking_is_output_invariant(chunk):
     assert not err.any() and valid.all() and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("field", [0, 1, 2, 3], ids=["secp256k1_p", "secp256k1_n", "p256_p", "p256_n"])
+def test_safegcd_inversion_stress(field):
+    """csrc/fe.hpp fe_inv_safegcd (Bernstein-Yang division steps on signed 30-bit limbs, what fe_inv runs): x * inv(x) == 1,
+    the result canonical and identical to the binary-GCD inversion's, zero reported as not invertible -- random, short,
+    word-patterned and m - small inputs over the crate's four moduli (field/*.rs: inverse = x^(m-2))."""
+    import ctypes as C
+    L = EmuBackend().L
+    L.emu_safegcd_selfcheck.restype = C.c_long
+    assert L.emu_safegcd_selfcheck(C.c_int(field), C.c_ulonglong(31 + field), C.c_size_t(500000)) == 0
+
+
 def test_lazy_limb_field_arithmetic_matches_the_canonical_form():
     """csrc/fe29.hpp (secp256k1's p on unsaturated 29-bit limbs, what the four-lane chains compute with) against csrc/fe.hpp
     (canonical 32-bit words): every operation, operands pushed through the lazy forms the chains use, on random and

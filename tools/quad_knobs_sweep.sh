@@ -5,7 +5,7 @@ TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${TAG}_quad_knobs.txt
 : > $OUT
-for rep in 1 2; do
+for rep in $(seq ${REPS:-2}); do
   for lds in 160000 80000 54000 0; do
     for split in 2 1 3; do
       for last in 3 2; do

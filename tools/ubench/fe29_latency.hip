@@ -12,8 +12,8 @@
 using namespace p2e;
 #define CK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(err_)); return 1; } } while (0)
 
-enum { OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_DBLISH, OP_CANON, OP_COUNT };
-static const char* op_name[OP_COUNT] = {"mul", "sqr", "add", "sub", "doubling-like mix (3 mul/sqr + 14 add/sub)", "store form (canon / none)"};
+enum { OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_DBLISH, OP_CANON, OP_INV, OP_COUNT };
+static const char* op_name[OP_COUNT] = {"mul", "sqr", "add", "sub", "doubling-like mix (3 mul/sqr + 14 add/sub)", "store form (canon / none)", "inversion (fe_inv: safegcd; both columns: words)"};
 
 // canonical words
 template <int OP>
@@ -40,6 +40,7 @@ __global__ void k_words(const U256* in, U256* out, unsigned long long* ticks, in
             y = fe_add<ModP>(x3, z3);
         }
         if (OP == OP_CANON) x = u256_select(u256_is_zero(x), y, x);
+        if (OP == OP_INV) x = fe_add<ModP>(fe_inv<ModP>(x), y);
     }
     const unsigned long long t1 = wall_clock64();
     out[i] = x;
@@ -69,6 +70,7 @@ __global__ void k_limbs(const U256* in, U256* out, unsigned long long* ticks, in
             x = f29_norm(f29_sub<2>(y0, c8));
             y = f29_norm(f29_add(x3, z3));
         }
+        if (OP == OP_INV) x = f29_from_u256(fe_add<ModP>(fe_inv<ModP>(f29_canon(x)), f29_canon(y)));
         if (OP == OP_CANON) {   // what one op of the chain pays for its stores: one value to canonical words and back
             const U256 c = f29_canon(x);
             x = f29_select(u256_is_zero(c), y, f29_from_u256(c));
@@ -80,8 +82,9 @@ __global__ void k_limbs(const U256* in, U256* out, unsigned long long* ticks, in
 }
 
 template <int OP>
-static int run_op(const U256* d_in, U256* d_out, unsigned long long* d_ticks, int blocks, int iters, std::vector<U256>& res, double& ns_words,
+static int run_op(const U256* d_in, U256* d_out, unsigned long long* d_ticks, int blocks, int iters_in, std::vector<U256>& res, double& ns_words,
                   double& ns_limbs) {
+    const int iters = OP == OP_INV ? 40 : iters_in;
     std::vector<unsigned long long> ticks(blocks);
     std::vector<U256> a((size_t)blocks * 64), b((size_t)blocks * 64);
     for (int rep = 0; rep < 3; rep++) {
@@ -134,7 +137,7 @@ int main() {
         double w, l;
         int rc = 0;
 #define ROW(OP) rc = run_op<OP>(d_in, d_out, d_ticks, blocks, iters, res, w, l); if (rc) return rc; printf("  %-50s %12.1f %12.1f %8.2f\n", op_name[OP], w, l, l / w);
-        ROW(OP_MUL) ROW(OP_SQR) ROW(OP_ADD) ROW(OP_SUB) ROW(OP_DBLISH) ROW(OP_CANON)
+        ROW(OP_MUL) ROW(OP_SQR) ROW(OP_ADD) ROW(OP_SUB) ROW(OP_DBLISH) ROW(OP_CANON) ROW(OP_INV)
     }
     return 0;
 }
