@@ -552,7 +552,7 @@ def main():
                                     "(BASELINE configs[3], the metric's literal shape)" if args.scaling == "strong" else
                                     f"batch 2^{args.batch_log2} ECDSA verifies per GPU (BASELINE configs[3] workload on one GPU)")
                                    + "; random valid signatures, seed 4; all 82615 hot-path generator columns, "
-                                   "column-major u64 (Goldilocks) in HBM; arithmetic in 8 x u32 limbs",
+                                   "column-major u64 (Goldilocks) in HBM; witness arithmetic in 8 x u32 limbs, curve chains and inversion batches in 9 unsaturated 29-bit limbs",
                        "container": "compact (u32 narrow + u64 wide matrices), NOT the headline format" if args.compact
                                     else "u64 column matrix",
                        "batch_per_gpu": n, "global_batch": total, "cols_per_fill": p2e.VERIFY_COLS, "ld": ld,

@@ -559,7 +559,7 @@ struct p2e_ctx {
     bool fb_run = false;
     // A run is walked by ONE lane, so a launch of r runs has only r * n/64 waves: below this batch size the
     // 1024 SIMDs are better filled by one workgroup row per op (2^10 glv_mul fills: 3.0 ms against 9.5 ms)
-    size_t runs_min_n = 17409;              // (= every batch the four-lane plan does not take, see quad_max_n)
+    size_t runs_min_n = 21505;              // (= every batch the four-lane plan does not take, see quad_max_n)
     size_t cp_runs_min_n = 49152;           // the same threshold for the curve programs (curve_api.inc), measured there only at 2^13 / 2^16
     // Below this batch size phases A and B are latency, not throughput: four lanes per signature walk the chains
     // (k_chains_quad) and every inversion batch is cut into 2^binv_split_log2 sub-ranges (k_batch_inv_split)
@@ -567,7 +567,10 @@ struct p2e_ctx {
     // wins from 2^14 up -- 3.94 against 4.60 ms at 16 384, 4.96 against 6.46 ms at 24 576, 3.81 against 3.62 ms at 12 288)
     // (round 3, with short expansion runs and front-loaded pieces: 3.56-3.76 against 4.10-4.15 ms at 16 384, 4.73 against
     // 4.5 ms at 20 480, profiles/r03_plan_threshold_resweep.txt -- the threshold moved up from 14 336 and now takes 2^14)
-    size_t quad_max_n = 17408;
+    // (with the chains on lazy limbs and the safegcd inversion: 3.44-3.52 against 3.96-4.03 ms at 16 384, 4.05-4.28 against
+    // 4.25-4.35 at 20 480, 5.01-5.04 against 4.72-4.73 at 24 576, profiles/r03_plan_threshold_lazy_limbs.txt: 17 408 -> 21 504)
+    size_t quad_max_n = 21504;
+    size_t cp_quad_max_n = 17408;   // the curve programs' own threshold (P-256 keeps canonical words: measured with those)
     // Between the two plans (lane per signature, but fewer than one chain wave per SIMD) phase B is the serial resource:
     // its kernels are latency-bound (half a wave per SIMD at 2^15) and queue on one stream from the first piece to the
     // last, with every expansion waiting behind them.  Below this batch size the inversion batches of consecutive pieces
@@ -757,7 +760,7 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     }
     if (const char* env = getenv("P2E_FB_RUN")) c->fb_run = atoi(env) != 0;
     if (const char* env = getenv("P2E_RUNS_MIN_N")) c->runs_min_n = (size_t)strtoull(env, nullptr, 10);
-    if (const char* env = getenv("P2E_QUAD_MAX_N")) c->quad_max_n = (size_t)strtoull(env, nullptr, 10);
+    if (const char* env = getenv("P2E_QUAD_MAX_N")) c->quad_max_n = c->cp_quad_max_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_BINV_ALT_MAX_N")) c->binv_alt_max_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_CP_RUNS_MIN_N")) c->cp_runs_min_n = (size_t)strtoull(env, nullptr, 10);
     if (const char* env = getenv("P2E_MSM_PIECES_MID")) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# mid-size plan (17 408 < n < 49 152): run length x pieces x inversion split, one process per setting
+# mid-size plan (21 504 < n < 49 152): run length x pieces x inversion split, one process per setting
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${TAG}_mid_plan.txt
