@@ -115,8 +115,10 @@ def p256_leg(p2e, torch, ctx, dev, n):
            "whole_fill_frac_of_hbm_peak": round(out_bytes / med / 1e9 / HBM_PEAK_GBS, 4),
            "roofline": {"kernel": "kc_expand + kc_expand_runs + kc_expand_fb_run", "bound": "hbm",
                         "algorithmic_bytes": int(exp_cols * 8 * n), "sum_launch_ms": round(exp_ms, 3),
-                        "achieved": round(exp_cols * 8 * n / exp_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(exp_cols * 8 * n / exp_ms / 1e6 / HBM_PEAK_GBS, 4)}}
+                        "achieved": round(exp_cols * 8 * n / max(exp_ms, 1e-9) / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(exp_cols * 8 * n / max(exp_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}}
+    if exp_ms <= 0:   # a context without P2E_CTX_PHASE_TIMING: no per-launch durations
+        res["roofline"] = None
     prog.close()
     return res
 
@@ -304,6 +306,9 @@ def main():
                     help="batches in flight per GPU: D > 1 issues step i on context/stream/output buffer i % D "
                          "(asynchronous C ABI), so the scalar phase and first chain pieces of the next batch "
                          "run under the expansion of the current one")
+    ap.add_argument("--no-phase-timing", action="store_true",
+                    help="contexts without P2E_CTX_PHASE_TIMING: no per-launch HIP events, so no roofline objects on the line; "
+                         "what a production caller runs (the events cost 6 %% at 2^13 signatures per call, nothing at 2^16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-p256", action="store_true", help="skip the P-256 verifier leg (SURVEY 8(f) rank 4 on the driver's line)")
     args = ap.parse_args()
@@ -346,7 +351,8 @@ def main():
     inputs = [torch.from_numpy(a).to(dev) for a in sigs]
     torch.cuda.synchronize()
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(depth - 1)]
-    ctxs = [p2e.Context(device=local_rank, stream=st.cuda_stream, asynchronous=depth > 1) for st in streams]
+    # (phase_timing: the per-launch HIP events the roofline objects are computed from)
+    ctxs = [p2e.Context(device=local_rank, stream=st.cuda_stream, asynchronous=depth > 1, phase_timing=not args.no_phase_timing) for st in streams]
     ctx = ctxs[0]
     # column stride: n + 16 elements.  A power-of-two stride (2^16 * 8 B = 512 KiB) makes consecutive columns
     # camp on the same HBM channels (measured -9 % on k_expand); ld is part of the C ABI (ld >= n).
@@ -525,7 +531,7 @@ def main():
 
         def roofline(kernel, st):
             # `launches` launches per step (one per schedule segment); per launch:
-            if not st["launches"]:
+            if not st["launches"] or args.no_phase_timing:
                 return None
             avg_s = sum(st["ms"]) / len(st["ms"]) / 1e3 / st["launches"]
             alg_bytes = int(st["cols"]) * 8 * n // st["launches"]

@@ -62,6 +62,10 @@ extern "C" {
 /* context flags */
 #define P2E_CTX_HOST_POINTERS 1u
 #define P2E_CTX_ASYNC 2u
+/* Time every launch of a fused call with HIP events (p2e_last_phase_ms).  Off by default: a timing event is a barrier
+ * packet in front of and behind every expansion launch, which costs nothing measurable at 2^16 signatures per call but
+ * 6 % at 2^13 (2.04 -> 1.92 ms).  The column-block events of p2e_segments_* exist either way (without timestamps). */
+#define P2E_CTX_PHASE_TIMING 4u
 
 #define P2E_VERIFY_COLS 82615  /* hot-path generator outputs of one verify_secp256k1_message_circuit */
 #define P2E_GLV_MUL_COLS 65243 /* ... of one glv_mul                                                 */
@@ -84,7 +88,8 @@ int p2e_sync(p2e_ctx *ctx);
 const char *p2e_last_error(void);
 /* bytes of device scratch the fused entry points need for a batch of n (allocated lazily, kept) */
 size_t p2e_scratch_bytes(int program /*0 verify, 1 glv_mul*/, size_t n);
-/* Timing of the last fused call, measured with hipEvents on the context's stream around every launch.
+/* Timing of the last fused call, measured with hipEvents on the context's stream around every launch -- for contexts
+ * created with P2E_CTX_PHASE_TIMING; otherwise every duration is 0 and only the launch and column counts are filled in.
  * The schedule is cut into segments whose Jacobian chains run on internal streams underneath; each
  * finished segment is expanded by k_expand (one curve op per workgroup row: window table, fixed-base
  * chain, trailing adds) and/or k_expand_runs (runs of MSM-loop iterations).

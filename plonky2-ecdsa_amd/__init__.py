@@ -36,7 +36,7 @@ FIELD_SCALAR = 1  # plonky2 Secp256K1Scalar
 FIELD_P256_BASE, FIELD_P256_SCALAR = 2, 3   # the crate's P256Base / P256Scalar (single-generator entry points)
 ERR_LIMB_RANGE, ERR_VALUE_GE_2_256, ERR_INVERSE_OF_ZERO, ERR_CARRY_RANGE, ERR_QUOTIENT_RANGE = 1, 2, 4, 8, 16
 ERR_DIVISION_BY_ZERO = 32
-CTX_HOST_POINTERS, CTX_ASYNC = 1, 2
+CTX_HOST_POINTERS, CTX_ASYNC, CTX_PHASE_TIMING = 1, 2, 4
 VERIFY_COLS = 82615
 GLV_MUL_COLS = 65243
 VERIFY_AUX_COLS = 8959      # built-in-generator columns (include/p2e.h p2e_aux_witness_batch)
@@ -547,13 +547,17 @@ class Context:
 
     ``host_pointers=True`` makes every entry point take numpy arrays (staged through the library's own
     device buffers: convenient for tests, PCIe-inclusive, never benchmarked).  Otherwise arguments are
-    torch CUDA tensors and the context runs on ``stream`` (default: torch's current stream)."""
+    torch CUDA tensors and the context runs on ``stream`` (default: torch's current stream).
+    ``phase_timing=True`` (P2E_CTX_PHASE_TIMING) times every launch for last_phase_ms(); off by default, it costs 6 % at 2^13
+    signatures per call."""
 
-    def __init__(self, device: int = 0, host_pointers: bool = False, stream=None, asynchronous: bool = False):
+    def __init__(self, device: int = 0, host_pointers: bool = False, stream=None, asynchronous: bool = False,
+                 phase_timing: bool = False):
         L = lib()
         self._L = L
         self.host_pointers = host_pointers
-        flags = (CTX_HOST_POINTERS if host_pointers else 0) | (CTX_ASYNC if asynchronous else 0)
+        flags = ((CTX_HOST_POINTERS if host_pointers else 0) | (CTX_ASYNC if asynchronous else 0)
+                 | (CTX_PHASE_TIMING if phase_timing else 0))
         if stream is None and not host_pointers:
             import torch
             stream = torch.cuda.current_stream(device).cuda_stream
@@ -581,7 +585,8 @@ class Context:
 
     def last_phase_ms(self):
         """include/p2e.h p2e_last_phase_ms: `expand*` = k_expand launches, `runs*` = k_expand_runs launches, `fbrun*` =
-        k_expand_fb_run launches (per kind: launches, columns written per signature, summed HIP-event durations in ms)."""
+        k_expand_fb_run launches (per kind: launches, columns written per signature, summed HIP-event durations in ms).
+        Durations are 0 unless the context was created with phase_timing=True (launches and columns are always there)."""
         buf = (C.c_float * 12)()
         self._L.p2e_last_phase_ms(self._h, buf, C.c_int(12))
         return dict(zip(("scalar", "expand_launches", "expand_cols", "expand", "total", "runs_launches", "runs_cols",

@@ -598,6 +598,9 @@ struct p2e_ctx {
     // fixed-base batch (67 ops that all keep their affine form: the longest) queued behind it used to hold up the second
     // loop piece's batch in turn.  0: the round-2 order.
     int quad_b_first_on_fixed = 1;
+    // EXPERIMENT knob (P2E_NO_EXPAND_EVENTS=1): no event pair around the expansion launches -- no per-launch timings
+    // (p2e_last_phase_ms) and no column-block events (p2e_segments_*) for such a context
+    bool expand_events = true;
     unsigned expand_lds_small = 54000;   // (160 000 -- one expansion workgroup per CU -- while the chains were the bottleneck; with lazy-limb chains 54 000 is 3-4 % faster at 2^13, profiles/r03_quad_plan_lazy_limbs_sweeps.txt)
     unsigned expand_lds = 0;   // the same knob for the large-batch plan
     Aff* d_cpts = nullptr;
@@ -789,6 +792,7 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         if (c->expand_lds > (unsigned)max_lds) c->expand_lds = (unsigned)max_lds;
     }
     if (const char* env = getenv("P2E_QUAD_B_FIRST_ON_FIXED")) c->quad_b_first_on_fixed = atoi(env) != 0;
+    if (const char* env = getenv("P2E_NO_EXPAND_EVENTS")) c->expand_events = atoi(env) == 0;
     if (const char* env = getenv("P2E_BINV_SPLIT_LOG2_LAST")) {
         int v = atoi(env);
         if (v >= 0 && v <= 4) c->binv_split_log2_last = v;
@@ -845,7 +849,8 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     }
     HIP_TRY(hipMalloc(&c->d_counter, sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(&c->h_counter, sizeof(unsigned long long)));
-    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    // ev[1] closes the scalar phase's column block (p2e_segments_*): it exists either way, with a timestamp only on request
+    for (auto& e : c->ev) HIP_TRY(hipEventCreateWithFlags(&e, (c->flags & P2E_CTX_PHASE_TIMING) ? hipEventDefault : hipEventDisableTiming));
     int prio_lo = 0, prio_hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     // Internal streams, created AND bound to their hardware queues (one empty launch each) in the order of the layout
@@ -921,7 +926,7 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fixed, hipEventDisableTiming));
     for (auto& e : c->ev_piece) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_c0) HIP_TRY(hipEventCreate(&e));
-    for (auto& e : c->ev_c1) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : c->ev_c1) HIP_TRY(hipEventCreateWithFlags(&e, (c->flags & P2E_CTX_PHASE_TIMING) ? hipEventDefault : hipEventDisableTiming));
     if (const char* env = getenv("P2E_MSM_PIECES")) {
         int v = atoi(env);
         if (v >= 1 && v <= p2e_ctx::MAX_PIECES) c->msm_pieces = v;
@@ -1013,13 +1018,17 @@ extern "C" int p2e_sync(p2e_ctx* c) {
         (void)hipGetLastError();
         return P2E_E_HIP;
     }
-    if (c->have_phases) {
-        HIP_TRY(hipEventElapsedTime(&c->phase_ms[0], c->ev[0], c->ev[1]));   // scalar kernel
-        HIP_TRY(hipEventElapsedTime(&c->phase_ms[4], c->ev[0], c->ev[5]));   // whole call
+    if (c->have_phases) {   // launches and columns per kernel kind always; durations for P2E_CTX_PHASE_TIMING contexts
+        const bool timed = (c->flags & P2E_CTX_PHASE_TIMING) != 0;
+        c->phase_ms[0] = c->phase_ms[4] = 0.f;
+        if (timed) {
+            HIP_TRY(hipEventElapsedTime(&c->phase_ms[0], c->ev[0], c->ev[1]));   // scalar kernel
+            HIP_TRY(hipEventElapsedTime(&c->phase_ms[4], c->ev[0], c->ev[5]));   // whole call
+        }
         double cnt[3] = {0, 0, 0}, cols[3] = {0, 0, 0}, sum_ms[3] = {0, 0, 0};
         for (int k = 0; k < c->n_expand; k++) {
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, c->ev_c0[k], c->ev_c1[k]));
+            if (timed) HIP_TRY(hipEventElapsedTime(&ms, c->ev_c0[k], c->ev_c1[k]));
             const int kind = c->expand_kind[k];
             cnt[kind] += 1;
             cols[kind] += c->expand_cols[k];
@@ -1615,7 +1624,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             hipLaunchKernelGGL(k_batch_inv, dim3(gx), dim3(BS), 0, st, G, B, lo, hi, have_prefix);
     };
     seg_begin_call(c, DP.h_ops, (u32)G.num_cols);
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (c->flags & P2E_CTX_PHASE_TIMING) HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (gx_wide) LAUNCH_EMIT(k_scalar, true, dim3(gx_wide), c->stream, G, B, (size_t)0);
     if (gx_tail) LAUNCH_EMIT(k_scalar, false, dim3(gx_tail), c->stream, G, B, n_wide);
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -1723,30 +1732,30 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             const int R = run_iters;
             const unsigned nr = (unsigned)((sg.it1 - sg.it0 + R - 1) / R);
             const int e = c->n_expand++;
-            HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
+            if (c->flags & P2E_CTX_PHASE_TIMING) HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
             if (gx_wide) LAUNCH_EMIT(k_expand_runs, true, dim3(gx_wide, nr), st_c, G, B, sg.it0, R, sg.it1, (size_t)0);
             if (gx_tail) LAUNCH_EMIT(k_expand_runs, false, dim3(gx_tail, nr), st_c, G, B, sg.it0, R, sg.it1, n_wide);
-            HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
+            if (c->expand_events) HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 1;
             c->expand_cols[e] = cols_of(G.msm_loop_begin + 3 * sg.it0, G.msm_loop_begin + 3 * sg.it1);
             seg_note_expand(c, e, DP.h_ops, G.msm_loop_begin + 3 * sg.it0, G.msm_loop_begin + 3 * sg.it1);
         }
         if (sg.fb_run) {
             const int e = c->n_expand++;
-            HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
+            if (c->flags & P2E_CTX_PHASE_TIMING) HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
             if (gx_wide) LAUNCH_EMIT(k_expand_fb_run, true, dim3(gx_wide), st_c, G, B, G.fb_begin + G.fb_windows, (size_t)0);
             if (gx_tail) LAUNCH_EMIT(k_expand_fb_run, false, dim3(gx_tail), st_c, G, B, G.fb_begin + G.fb_windows, n_wide);
-            HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
+            if (c->expand_events) HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 2;
             c->expand_cols[e] = cols_of(G.fb_begin, G.fb_begin + G.fb_windows);
             seg_note_expand(c, e, DP.h_ops, G.fb_begin, G.fb_begin + G.fb_windows);
         }
         if (sg.s_hi > sg.s_lo) {
             const int e = c->n_expand++;
-            HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
+            if (c->flags & P2E_CTX_PHASE_TIMING) HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
             if (gx_wide) LAUNCH_EMIT(k_expand, true, dim3(gx_wide, (unsigned)(sg.s_hi - sg.s_lo)), st_c, G, B, sg.s_lo, (size_t)0);
             if (gx_tail) LAUNCH_EMIT(k_expand, false, dim3(gx_tail, (unsigned)(sg.s_hi - sg.s_lo)), st_c, G, B, sg.s_lo, n_wide);
-            HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
+            if (c->expand_events) HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 0;
             c->expand_cols[e] = cols_of(sg.s_lo, sg.s_hi);
             seg_note_expand(c, e, DP.h_ops, sg.s_lo, sg.s_hi);
@@ -1760,9 +1769,9 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         HIP_TRY(hipEventRecord(c->ev_c1join, st_c1));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_c1join, 0));
     }
-    HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+    if (c->flags & P2E_CTX_PHASE_TIMING) HIP_TRY(hipEventRecord(c->ev[5], c->stream));
     hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, B.err, B.valid, err, valid, n, c->d_counter);
-    c->have_phases = true;
+    c->have_phases = c->expand_events;
     return S.done(finish_call(c));
 #undef LAUNCH_EMIT
 }

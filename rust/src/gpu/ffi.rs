@@ -58,6 +58,7 @@ pub struct P2eSegmentDesc {
 
 pub const P2E_CTX_HOST_POINTERS: u32 = 1;
 pub const P2E_CTX_ASYNC: u32 = 2;
+pub const P2E_CTX_PHASE_TIMING: u32 = 4;
 pub const P2E_VERIFY_COLS: usize = 82_615;
 pub const P2E_VERIFY_AUX_COLS: usize = 8_959;
 pub const P2E_VERIFY_UX_COLS: usize = 249_385;

@@ -801,6 +801,27 @@ def test_assemble_wires_against_numpy():
     assert np.array_equal(np.asarray(hw)[:, named], want[:5][:, named].view(np.uint64))
 
 
+def test_per_launch_timing_is_opt_in_and_changes_no_value():
+    """include/p2e.h P2E_CTX_PHASE_TIMING: a context created with it reports a duration for the scalar kernel, for the
+    expansion launches and for the whole call (p2e_last_phase_ms); the default context reports the same launch and
+    column counts with zero durations -- and both write the same witness."""
+    import torch
+    import plonky2_ecdsa_amd as p2e
+    n = 2048 + 5
+    dev = [torch.from_numpy(a).cuda() for a in p2e.synth_signatures(seed=77, n=n)]
+    plain, timed = p2e.Context(device=0), p2e.Context(device=0, phase_timing=True)
+    a = plain.ecdsa_verify_witness_batch(*dev)
+    b = timed.ecdsa_verify_witness_batch(*dev)
+    torch.cuda.synchronize()
+    assert a[3] == 0 and b[3] == 0 and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    pa, pb = plain.last_phase_ms(), timed.last_phase_ms()
+    for k in ("expand_launches", "expand_cols", "runs_launches", "runs_cols", "fbrun_launches", "fbrun_cols"):
+        assert pa[k] == pb[k]
+    assert pa["expand_cols"] + pa["runs_cols"] + pa["fbrun_cols"] > 80000
+    assert pa["scalar"] == 0 and pa["total"] == 0 and pa["expand"] == 0 and pa["runs"] == 0
+    assert pb["scalar"] > 0 and pb["total"] > pb["scalar"] and pb["expand"] + pb["runs"] > 0
+
+
 @pytest.mark.parametrize("plan", ["four_lanes", "lane_per_signature_runs"])
 def test_column_blocks_are_final_when_their_event_fires(monkeypatch, plan):
     """include/p2e.h p2e_segments_describe / p2e_segment_stream_wait (what the pipelined assembly of a

@@ -16,7 +16,7 @@ import plonky2_ecdsa_amd as p2e
 PEAK = 8000.0
 reps = int(os.environ.get("REPS", "5"))
 logs = [int(a) for a in sys.argv[1:]] or [13, 15]
-ctx = p2e.Context(device=0)
+ctx = p2e.Context(device=0, phase_timing=True)
 # any point of the curve serves as the circuit's rand() point: 0xC0FFEE * G, computed by the synthetic-signature helper's
 # own arithmetic is not exposed, so take a public key of the synthetic stream (a uniformly random multiple of G)
 for curve, cname in ((p2e.CURVE_SECP256K1, "secp256k1"), (p2e.CURVE_P256, "p256")):

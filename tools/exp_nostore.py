@@ -10,7 +10,7 @@ if len(sys.argv) > 1:
     p2e.LIB_PATH = sys.argv[1]
 n = 1 << 16
 sigs = p2e.synth_signatures(seed=4, n=n)
-ctx = p2e.Context(device=0)
+ctx = p2e.Context(device=0, phase_timing=True)
 dev = [torch.from_numpy(a).cuda() for a in sigs]
 ld = n + 16
 big = torch.empty((p2e.VERIFY_COLS, ld), dtype=torch.int64, device="cuda")

@@ -6,7 +6,7 @@ import torch
 import plonky2_ecdsa_amd as p2e
 n = 1 << 16
 sigs = p2e.synth_signatures(seed=4, n=n)
-ctx = p2e.Context(device=0)
+ctx = p2e.Context(device=0, phase_timing=True)
 dev = [torch.from_numpy(a).cuda() for a in sigs]
 err = torch.empty(n, dtype=torch.uint8, device="cuda"); valid = torch.empty(n, dtype=torch.uint8, device="cuda")
 for pad in [0, 16, 32, 64, 96, 128, 256, 272, 1040, 4112]:
