@@ -601,6 +601,7 @@ struct p2e_ctx {
     // EXPERIMENT knob (P2E_NO_EXPAND_EVENTS=1): no event pair around the expansion launches -- no per-launch timings
     // (p2e_last_phase_ms) and no column-block events (p2e_segments_*) for such a context
     bool expand_events = true;
+    bool quad_few_waits = true;   // P2E_QUAD_FEW_WAITS=0: one wait per earlier piece, as before
     unsigned expand_lds_small = 54000;   // (160 000 -- one expansion workgroup per CU -- while the chains were the bottleneck; with lazy-limb chains 54 000 is 3-4 % faster at 2^13, profiles/r03_quad_plan_lazy_limbs_sweeps.txt)
     unsigned expand_lds = 0;   // the same knob for the large-batch plan
     Aff* d_cpts = nullptr;
@@ -793,6 +794,7 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     }
     if (const char* env = getenv("P2E_QUAD_B_FIRST_ON_FIXED")) c->quad_b_first_on_fixed = atoi(env) != 0;
     if (const char* env = getenv("P2E_NO_EXPAND_EVENTS")) c->expand_events = atoi(env) == 0;
+    if (const char* env = getenv("P2E_QUAD_FEW_WAITS")) c->quad_few_waits = atoi(env) != 0;
     if (const char* env = getenv("P2E_BINV_SPLIT_LOG2_LAST")) {
         int v = atoi(env);
         if (v >= 0 && v <= 4) c->binv_split_log2_last = v;
@@ -1696,6 +1698,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         }
     c->n_expand = 0;
     bool used_c2 = false;
+    int last_b[2] = {-1, quad ? first_msm : -1};   // most recent inversion batch on st_fixed / st_binv (the table's: above)
     emit_lds = quad ? c->expand_lds_small : c->expand_lds;
     for (int q = 0; q < ns; q++) {
         const int k = order[q];
@@ -1711,6 +1714,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             HIP_TRY(hipStreamWaitEvent(st_b, c->ev_piece[k], 0));
             launch_binv(st_b, sg.lo, sg.hi, 1, k == ns - 1);
             HIP_TRY(hipEventRecord(c->ev_binv[k], st_b));
+            last_b[st_b == c->st_binv ? 1 : 0] = k;
         }
         // (small-batch plan: phase C alternates between the caller's stream and a second one, so that an expansion
         // waiting for its inversion batch does not hold up the expansions queued behind it)
@@ -1720,8 +1724,16 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         // an expansion also reads affine results of EARLIER pieces (the first operand of its first op, the window
         // table, the fixed-base result under the final add): with one expansion stream the queue order implied
         // their inversion batches, with two it has to be said
-        if (quad)
-            for (int q2 = 0; q2 < q; q2++) HIP_TRY(hipStreamWaitEvent(st_c, c->ev_binv[order[q2]], 0));
+        // (the inversion batches sit on two in-order streams: the most recent one of each implies every earlier one, so
+        // two waits say what q of them used to -- 28 barrier packets less on the expansion streams of a verify call)
+        if (quad) {
+            if (c->quad_few_waits) {
+                for (int sb = 0; sb < 2; sb++)
+                    if (last_b[sb] >= 0 && last_b[sb] != k) HIP_TRY(hipStreamWaitEvent(st_c, c->ev_binv[last_b[sb]], 0));
+            } else {
+                for (int q2 = 0; q2 < q; q2++) HIP_TRY(hipStreamWaitEvent(st_c, c->ev_binv[order[q2]], 0));
+            }
+        }
         auto cols_of = [&](int lo, int hi) {
             double cw = 0;
             for (int t = lo; t < hi; t++)
