@@ -222,6 +222,12 @@ def test_safegcd_inversion_stress(field):
     assert L.emu_safegcd_selfcheck(C.c_int(field), C.c_ulonglong(31 + field), C.c_size_t(500000)) == 0
 
 
+def test_lazy_limb_constants_are_what_the_header_says():
+    """tools/f29_constants.py: 2^261 mod p and the borrowed-limb multiples of p that csrc/fe29.hpp subtracts with, re-derived."""
+    import runpy
+    runpy.run_path(os.path.join(ROOT, "tools", "f29_constants.py"), run_name="__main__")
+
+
 def test_lazy_limb_field_arithmetic_matches_the_canonical_form():
     """csrc/fe29.hpp (secp256k1's p on unsaturated 29-bit limbs, what the four-lane chains compute with) against csrc/fe.hpp
     (canonical 32-bit words): every operation, operands pushed through the lazy forms the chains use, on random and
