@@ -593,6 +593,9 @@ struct p2e_ctx {
     // piece's inversion batch (latency matters there; the earlier ones only need throughput: fewer inversions).
     int small_takes[p2e_ctx::MAX_PIECES + 1] = {0};
     int binv_split_log2_last = 3;
+    // the fixed-base chain's batch: 67 ops that all keep their affine form, the longest walk, and its expansion is the largest
+    // single launch of the call -- eight sub-ranges: 1.89 against 1.95 ms at 2^13, level at 2^14 (profiles/r03_fixed_base_batch_split.txt)
+    int binv_split_log2_fixed = 3;
     // small-batch plan: which of the two phase-B streams takes the FIRST batch after the window table's (the fixed-base
     // chain's).  1: the fixed-base chain's own stream -- the table's batch occupies the other one until ~0.7 ms, and the
     // fixed-base batch (67 ops that all keep their affine form: the longest) queued behind it used to hold up the second
@@ -795,6 +798,10 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
     if (const char* env = getenv("P2E_QUAD_B_FIRST_ON_FIXED")) c->quad_b_first_on_fixed = atoi(env) != 0;
     if (const char* env = getenv("P2E_NO_EXPAND_EVENTS")) c->expand_events = atoi(env) == 0;
     if (const char* env = getenv("P2E_QUAD_FEW_WAITS")) c->quad_few_waits = atoi(env) != 0;
+    if (const char* env = getenv("P2E_BINV_SPLIT_LOG2_FIXED")) {
+        int v = atoi(env);
+        if (v >= 0 && v <= 4) c->binv_split_log2_fixed = v;
+    }
     if (const char* env = getenv("P2E_BINV_SPLIT_LOG2_LAST")) {
         int v = atoi(env);
         if (v >= 0 && v <= 4) c->binv_split_log2_last = v;
@@ -1617,8 +1624,9 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
 
     const unsigned gx4 = (unsigned)((4 * n + BS - 1) / BS);
     const bool alt_b = quad || n < c->binv_alt_max_n;   // phase B of consecutive pieces on two streams
-    auto launch_binv = [&](hipStream_t st, int lo, int hi, int have_prefix, bool last_piece = false) {
-        const int sl = !quad ? (alt_b ? c->binv_mid_split_log2 : 0) : last_piece ? c->binv_split_log2_last : c->binv_split_log2;
+    auto launch_binv = [&](hipStream_t st, int lo, int hi, int have_prefix, bool last_piece = false, bool fixed_piece = false) {
+        const int sl = !quad ? (alt_b ? c->binv_mid_split_log2 : 0)
+                             : last_piece ? c->binv_split_log2_last : fixed_piece ? c->binv_split_log2_fixed : c->binv_split_log2;
         if ((quad || alt_b) && sl > 0)
             hipLaunchKernelGGL(k_batch_inv_split, dim3((unsigned)(((n << sl) + BS - 1) / BS)), dim3(BS), 0, st, G, B, lo, hi,
                                have_prefix, sl);
@@ -1712,7 +1720,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
         hipStream_t st_b = (alt_b && b_odd) ? c->st_binv : c->st_fixed;
         if (k != first_msm) {
             HIP_TRY(hipStreamWaitEvent(st_b, c->ev_piece[k], 0));
-            launch_binv(st_b, sg.lo, sg.hi, 1, k == ns - 1);
+            launch_binv(st_b, sg.lo, sg.hi, 1, k == ns - 1, k < first_msm);
             HIP_TRY(hipEventRecord(c->ev_binv[k], st_b));
             last_b[st_b == c->st_binv ? 1 : 0] = k;
         }
