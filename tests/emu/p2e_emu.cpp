@@ -252,6 +252,61 @@ static long safegcd_one(const U256& raw) {
     const bool ok2 = fe_inv_bingcd<MOD>(x, r2);
     return (ok && ok2 && u256_eq(r, r2) && !geq_mod<MOD>(r.w) && u256_eq(fe_mul<MOD>(x, r), u256_small(1))) ? 0 : 1;
 }
+// ---- ec29.hpp / quad29.hpp against ec.hpp / quad.hpp: every variant of the addition and the doubling, lane per signature and
+// four-lane form, on arbitrary coordinates (the formulas never use the curve equation), under the limb-bound tracking
+template <bool Z1ONE, bool Z2ONE>
+static long ec29_add_case(const Jac& p1, const Jac& p2, const U256& acc, const U256& zz1) {
+    long fails = 0;
+    Jac a = p1, b = p2;
+    if (Z1ONE) a.Z = u256_small(1);
+    if (Z2ONE) b.Z = u256_small(1);
+    const JacW want = jac_add<Z1ONE, Z2ONE>(a, b);
+    const JacWL got = jac_add29<Z1ONE, Z2ONE>(jacl_from(a), jacl_from(b));
+    fails += !u256_eq(f29_canon(got.p.X), want.p.X) + !u256_eq(f29_canon(got.p.Y), want.p.Y) + !u256_eq(f29_canon(got.p.Z), want.p.Z) +
+             !u256_eq(f29_canon(got.W), want.W);
+    for (int have = 0; have < 2; have++) {
+        const U256 z1sq = fe_sqr<ModP>(a.Z);
+        const QuadRes wq = jac_add_quad<Z1ONE, Z2ONE>(0, a, have != 0, have ? z1sq : zz1, b, acc);
+        for (int role = 0; role < 4; role++) {
+            const QuadRes29 q = jac_add_quad29<Z1ONE, Z2ONE>(role, false, jacl_from(a), have != 0, f29_from_u256(have ? z1sq : zz1), jacl_from(b),
+                                                             f29_from_u256(acc));
+            const U256 mine = role == 0 ? wq.res.p.X : role == 1 ? acc : role == 2 ? wq.res.p.Z : wq.res.W;
+            fails += !u256_eq(f29_canon(q.p.X), wq.res.p.X) + !u256_eq(f29_canon(q.p.Y), wq.res.p.Y) + !u256_eq(f29_canon(q.p.Z), wq.res.p.Z) +
+                     !u256_eq(f29_canon(q.acc), wq.acc) + !u256_eq(f29_canon(q.zz3), wq.zz3) + !u256_eq(q.mine, mine) + (q.z3_zero != wq.z3_zero);
+            if (!Z1ONE) fails += !u256_eq(f29_canon(q.zz1), wq.zz1);
+        }
+    }
+    return fails;
+}
+extern "C" long emu_ec29_selftest(unsigned long long seed, size_t n) {
+    long fails = 0;
+#pragma omp parallel for reduction(+ : fails)
+    for (long long i = 0; i < (long long)n; i++) {
+        host::SplitMix64 rng{seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1))};
+        Jac p1, p2;
+        p1.X = f29_test_value(rng); p1.Y = f29_test_value(rng); p1.Z = f29_test_value(rng);
+        p2.X = f29_test_value(rng); p2.Y = f29_test_value(rng); p2.Z = f29_test_value(rng);
+        const U256 acc = f29_test_value(rng), zz1 = f29_test_value(rng);
+        if ((i & 15) == 0) p2 = p1;                       // equal operands: H = 0, Z3 = 0 (the reference's inverse-of-zero case)
+        fails += ec29_add_case<false, false>(p1, p2, acc, zz1) + ec29_add_case<false, true>(p1, p2, acc, zz1) +
+                 ec29_add_case<true, false>(p1, p2, acc, zz1) + ec29_add_case<true, true>(p1, p2, acc, zz1);
+        const JacW wd = jac_dbl(p1);
+        const JacWL gd = jac_dbl29(jacl_from(p1));
+        fails += !u256_eq(f29_canon(gd.p.X), wd.p.X) + !u256_eq(f29_canon(gd.p.Y), wd.p.Y) + !u256_eq(f29_canon(gd.p.Z), wd.p.Z) +
+                 !u256_eq(f29_canon(gd.W), wd.W);
+        const QuadRes wq = jac_dbl_quad(0, p1, acc);
+        for (int role = 0; role < 4; role++)
+            for (int na = 0; na < 2; na++) {
+                const QuadRes29 q = jac_dbl_quad29(role, na != 0, jacl_from(p1), f29_from_u256(acc));
+                const U256 mine = role == 1 ? acc : role == 3 ? wq.res.W : (role == 0 && !na) ? wq.res.p.X : wq.res.p.Z;
+                fails += !u256_eq(f29_canon(q.p.X), wq.res.p.X) + !u256_eq(f29_canon(q.p.Y), wq.res.p.Y) + !u256_eq(f29_canon(q.p.Z), wq.res.p.Z) +
+                         !u256_eq(f29_canon(q.acc), wq.acc) + !u256_eq(f29_canon(q.zz3), wq.zz3) + !u256_eq(f29_canon(q.zz1), wq.zz1) +
+                         !u256_eq(q.mine, mine) + (q.z3_zero != wq.z3_zero);
+            }
+    }
+    return fails;
+}
+
 extern "C" {
 // raw access to the binary-GCD inversion (csrc/fe.hpp) for the stress test: ok[i] = round bound held
 long emu_bingcd(int field, const uint8_t* x32, uint8_t* inv32, uint8_t* ok, size_t n) {

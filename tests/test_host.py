@@ -222,6 +222,17 @@ def test_safegcd_inversion_stress(field):
     assert L.emu_safegcd_selfcheck(C.c_int(field), C.c_ulonglong(31 + field), C.c_size_t(500000)) == 0
 
 
+def test_lazy_limb_curve_formulas_match_the_canonical_ones_in_every_variant():
+    """csrc/ec29.hpp, quad29.hpp against csrc/ec.hpp, quad.hpp: the doubling and all four Z-one variants of the addition, lane per
+    signature and four-lane form (every role, with and without the carried Z1^2, with and without the affine slot), on
+    arbitrary coordinates incl. equal operands (Z3 = 0): X3, Y3, Z3, W, the prefix product, Z^2 values, the value each lane
+    stores and the zero flag.  Runs under the limb-bound tracking of the emulation build."""
+    import ctypes as C
+    L = EmuBackend().L
+    L.emu_ec29_selftest.restype = C.c_long
+    assert L.emu_ec29_selftest(C.c_ulonglong(13), C.c_size_t(30000)) == 0
+
+
 def test_lazy_limb_constants_are_what_the_header_says():
     """tools/f29_constants.py: 2^261 mod p and the borrowed-limb multiples of p that csrc/fe29.hpp subtracts with, re-derived."""
     import runpy
