@@ -601,9 +601,6 @@ struct p2e_ctx {
     // fixed-base batch (67 ops that all keep their affine form: the longest) queued behind it used to hold up the second
     // loop piece's batch in turn.  0: the round-2 order.
     int quad_b_first_on_fixed = 1;
-    // EXPERIMENT knob (P2E_NO_EXPAND_EVENTS=1): no event pair around the expansion launches -- no per-launch timings
-    // (p2e_last_phase_ms) and no column-block events (p2e_segments_*) for such a context
-    bool expand_events = true;
     bool quad_few_waits = true;   // P2E_QUAD_FEW_WAITS=0: one wait per earlier piece, as before
     unsigned expand_lds_small = 54000;   // (160 000 -- one expansion workgroup per CU -- while the chains were the bottleneck; with lazy-limb chains 54 000 is 3-4 % faster at 2^13, profiles/r03_quad_plan_lazy_limbs_sweeps.txt)
     unsigned expand_lds = 0;   // the same knob for the large-batch plan
@@ -796,7 +793,6 @@ extern "C" int p2e_ctx_create(int device, unsigned flags, void* stream, p2e_ctx*
         if (c->expand_lds > (unsigned)max_lds) c->expand_lds = (unsigned)max_lds;
     }
     if (const char* env = getenv("P2E_QUAD_B_FIRST_ON_FIXED")) c->quad_b_first_on_fixed = atoi(env) != 0;
-    if (const char* env = getenv("P2E_NO_EXPAND_EVENTS")) c->expand_events = atoi(env) == 0;
     if (const char* env = getenv("P2E_QUAD_FEW_WAITS")) c->quad_few_waits = atoi(env) != 0;
     if (const char* env = getenv("P2E_BINV_SPLIT_LOG2_FIXED")) {
         int v = atoi(env);
@@ -1755,7 +1751,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             if (c->flags & P2E_CTX_PHASE_TIMING) HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
             if (gx_wide) LAUNCH_EMIT(k_expand_runs, true, dim3(gx_wide, nr), st_c, G, B, sg.it0, R, sg.it1, (size_t)0);
             if (gx_tail) LAUNCH_EMIT(k_expand_runs, false, dim3(gx_tail, nr), st_c, G, B, sg.it0, R, sg.it1, n_wide);
-            if (c->expand_events) HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
+            HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 1;
             c->expand_cols[e] = cols_of(G.msm_loop_begin + 3 * sg.it0, G.msm_loop_begin + 3 * sg.it1);
             seg_note_expand(c, e, DP.h_ops, G.msm_loop_begin + 3 * sg.it0, G.msm_loop_begin + 3 * sg.it1);
@@ -1765,7 +1761,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             if (c->flags & P2E_CTX_PHASE_TIMING) HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
             if (gx_wide) LAUNCH_EMIT(k_expand_fb_run, true, dim3(gx_wide), st_c, G, B, G.fb_begin + G.fb_windows, (size_t)0);
             if (gx_tail) LAUNCH_EMIT(k_expand_fb_run, false, dim3(gx_tail), st_c, G, B, G.fb_begin + G.fb_windows, n_wide);
-            if (c->expand_events) HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
+            HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 2;
             c->expand_cols[e] = cols_of(G.fb_begin, G.fb_begin + G.fb_windows);
             seg_note_expand(c, e, DP.h_ops, G.fb_begin, G.fb_begin + G.fb_windows);
@@ -1775,7 +1771,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
             if (c->flags & P2E_CTX_PHASE_TIMING) HIP_TRY(hipEventRecord(c->ev_c0[e], st_c));
             if (gx_wide) LAUNCH_EMIT(k_expand, true, dim3(gx_wide, (unsigned)(sg.s_hi - sg.s_lo)), st_c, G, B, sg.s_lo, (size_t)0);
             if (gx_tail) LAUNCH_EMIT(k_expand, false, dim3(gx_tail, (unsigned)(sg.s_hi - sg.s_lo)), st_c, G, B, sg.s_lo, n_wide);
-            if (c->expand_events) HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
+            HIP_TRY(hipEventRecord(c->ev_c1[e], st_c));
             c->expand_kind[e] = 0;
             c->expand_cols[e] = cols_of(sg.s_lo, sg.s_hi);
             seg_note_expand(c, e, DP.h_ops, sg.s_lo, sg.s_hi);
@@ -1791,7 +1787,7 @@ static long run_program(p2e_ctx* c, int program, const uint8_t* msg, const uint8
     }
     if (c->flags & P2E_CTX_PHASE_TIMING) HIP_TRY(hipEventRecord(c->ev[5], c->stream));
     hipLaunchKernelGGL(k_finalize, dim3(gx), dim3(BS), 0, c->stream, B.err, B.valid, err, valid, n, c->d_counter);
-    c->have_phases = c->expand_events;
+    c->have_phases = true;
     return S.done(finish_call(c));
 #undef LAUNCH_EMIT
 }
